@@ -1,0 +1,157 @@
+"""Pin the CPU oracle against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  Ids exact; floats <= 1e-6 (abs, values are O(1))."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import img2latex_oracle as O
+from helpers import ALL, END, PAD, SMALL, START, images, load, padded_to_lists, sample, torch_state_dict
+from img2latex_amd import synth
+
+TOL = 1e-6
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.abs(a - b).max()) <= tol * scale, float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_encoder_blocks_and_embedding(name):
+    d, cfg, _ = load(name)
+    sd = torch_state_dict(name)
+    x = images(cfg)
+    with torch.no_grad():
+        blocks = O.cnn_blocks(sd, cfg, x)
+        enc = O.cnn_encoder(sd, cfg, x)
+    for i, b in enumerate(blocks):
+        assert list(b.shape) == list(d[f"g1_block{i}_shape"])
+        if f"g1_block{i}" in d:
+            close(b.numpy(), d[f"g1_block{i}"])
+        else:
+            close(sample(b), d[f"g1_block{i}_sample"])
+    close(enc.numpy(), d["g1_enc"])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_decode_steps(name):
+    d, cfg, _ = load(name)
+    sd = torch_state_dict(name)
+    enc = torch.from_numpy(d["g1_enc"])
+    tok = torch.full((4, 1), START, dtype=torch.long)
+    hidden = None
+    with torch.no_grad():
+        for s in range(3):
+            logits, hidden = O.decode_step(sd, cfg, enc, tok, hidden)
+            close(logits.numpy(), d[f"g2_logits{s}"])
+            close(hidden[0].numpy(), d[f"g2_h{s}"])
+            close(hidden[1].numpy(), d[f"g2_c{s}"])
+            tok = logits.squeeze(1).argmax(-1, keepdim=True)
+            assert np.array_equal(tok.numpy(), d[f"g2_tok{s}"])
+        if cfg["attention"]:
+            ctx = O.attention_context(sd, hidden[0][-1].unsqueeze(1), enc.unsqueeze(1))
+            assert bool(d["g7_identity"]) and torch.equal(ctx.squeeze(1), enc)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_greedy_ids(name):
+    d, cfg, _ = load(name)
+    sd = torch_state_dict(name)
+    x = images(cfg)
+    with torch.no_grad():
+        ids = O.inference(sd, cfg, x, START, END, max_length=32)
+        one = O.inference(sd, cfg, x[1:2], START, END, max_length=32)
+        idt = O.inference(sd, cfg, x, START, END, max_length=12, temperature=0.7)
+    assert np.array_equal(np.array(ids), d["g3_b4_ids"])
+    assert list(one) == list(d["g3_b1_ids"])
+    assert np.array_equal(np.array(idt), d["g3_b4_temp_ids"])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_beam_ids(name):
+    d, cfg, _ = load(name)
+    sd = torch_state_dict(name)
+    bimgs = images(cfg, 8, seed=4321)
+    with torch.no_grad():
+        for k in (5, 3):
+            want = padded_to_lists(d[f"g4_k{k}_ids"], d[f"g4_k{k}_len"])
+            for j in range(8 if name in SMALL else 3):
+                got = O.inference(sd, cfg, bimgs[j:j + 1], START, END, max_length=40, beam_size=k)
+                assert got == want[j], (name, k, j)
+        fb = O.inference(sd, cfg, images(cfg), START, END, max_length=10, beam_size=3)
+    assert np.array_equal(np.array(fb), d["g4_fallback_ids"])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_predictor_loop_ids(name):
+    d, cfg, _ = load(name)
+    sd = torch_state_dict(name)
+    with torch.no_grad():
+        enc = O.cnn_encoder(sd, cfg, images(cfg))
+        rows = O.predictor_greedy_loop(sd, cfg, enc, START, END, max_length=32)
+    # the reference strips START (predictor.py:384-385) before tokenizer.decode
+    rows = [r[1:] if r and r[0] == START else r for r in rows]
+    assert rows == padded_to_lists(d["g5_ids"], d["g5_len"])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_train_step(name):
+    d, cfg, _ = load(name)
+    sd = torch_state_dict(name)
+    big = name in ("primary", "secondary")
+    T = 24 if big else 12
+    forms = torch.from_numpy(synth.make_formulas(4, T, cfg["vocab_size"], seed=777, min_len=5))
+    names = json.loads(str(d["g6_param_names"]))
+    assert names == list(sd.keys())
+    res = O.train_step(sd, cfg, images(cfg), forms, state={})
+    if "g6_logits" in d:
+        close(res["logits"].numpy(), d["g6_logits"], 2e-6)
+    else:
+        close(sample(res["logits"]), d["g6_logits_sample"], 2e-6)
+    assert abs(res["loss"] - float(d["g6_loss"])) <= 2e-6 * max(1.0, abs(float(d["g6_loss"])))
+    gn = np.array([float(res["grads"][k].norm()) for k in names])
+    np.testing.assert_allclose(gn, d["g6_grad_norms"], rtol=2e-4, atol=1e-7)
+    assert abs(res["total_norm"] - float(d["g6_total_norm"])) <= 2e-4 * float(d["g6_total_norm"])
+    after = np.stack([sample(sd[k], 8)[:8] if sd[k].numel() >= 8 else np.resize(sd[k].numpy().ravel(), 8)
+                      for k in names])
+    np.testing.assert_allclose(after, d["g6_param_sample_after"], rtol=0, atol=2e-6)
+    # attention parameters: exactly-zero gradient, yet moved by coupled weight decay
+    if cfg["attention"]:
+        assert float(res["grads"]["decoder.attention.attn.weight"].abs().max()) == 0.0
+
+
+def test_cfg2_ids_and_margins():
+    """BASELINE config 2 shapes through the oracle (B=256): ids exact vs the reference."""
+    for fname in ("primary_cfg2_clock", "primary_cfg2"):
+        d, cfg, sd_kw = load(fname)
+        sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, **sd_kw).items()}
+        ref_ids = d["ids"].astype(np.int64)
+        steps = ref_ids.shape[1] - 1
+        B = 32                                   # rows are independent: check a slice, seconds not minutes
+        x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)[:B])
+        with torch.no_grad():
+            enc = O.cnn_encoder(sd, cfg, x)
+            step = 256 * cfg["embedding_dim"] // 1024          # make_golden.sample() stride over all 256 rows
+            n = B * cfg["embedding_dim"] // step
+            close(enc.reshape(-1)[::step][:n].numpy(), d["enc_sample"][:n], 1e-5)
+            ids, margins = O.greedy_search(sd, cfg, enc, START, END, steps, return_margins=True)
+        got = np.array(ids)
+        assert np.array_equal(got, ref_ids[:B, : got.shape[1]])
+        np.testing.assert_allclose(margins.numpy(), d["margins"][:B, : margins.shape[1]], atol=2e-5)
+
+
+def test_synth_is_stable():
+    """The generator is the contract between container and GPU box: pin a few values."""
+    a = synth.uniform(42, "x", (4,), -1.0, 1.0)
+    b = synth.normal_like(42, "x", (3,))
+    c = synth.randint(7, "y", (5,), 4, 512)
+    assert a.dtype == np.float32 and b.dtype == np.float32
+    np.testing.assert_array_equal(a, synth.uniform(42, "x", (4,), -1.0, 1.0))
+    assert float(np.abs(a).max()) < 1.0 and c.min() >= 4 and c.max() < 512
+    f = synth.make_formulas(6, 20, 50)
+    assert (f[:, 0] == START).all() and ((f == END).sum(axis=1) == 1).all()
