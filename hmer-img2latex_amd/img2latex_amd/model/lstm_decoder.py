@@ -1,0 +1,191 @@
+"""LSTMDecoder / Attention with the reference's surface, HIP step kernels.
+
+Reference: img2latex/model/decoder.py:16-343.  nn.Embedding / nn.LSTM / nn.Linear
+children only own the parameters under the reference's state_dict keys
+(``embedding.weight``, ``lstm.{weight_ih,weight_hh,bias_ih,bias_hh}_l{k}``,
+``output_layer.{weight,bias}``, ``attention.attn.*``, ``attention.v.weight``); the
+step math runs in libimg2latex_hip.so (csrc/decode.hip).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+Hidden = Tuple[torch.Tensor, torch.Tensor]
+
+
+class Attention(nn.Module):
+    """Additive attention (decoder.py:287-343).  General source length via the HIP
+    kernel; inside LSTMDecoder the source length is 1 and the context equals the
+    encoder output bit-for-bit (softmax over one element), so the decoder never
+    launches it (see LSTMDecoder docstring)."""
+
+    def __init__(self, hidden_dim: int, encoder_dim: int):
+        super().__init__()
+        self.hidden_dim, self.encoder_dim = hidden_dim, encoder_dim
+        self.attn = nn.Linear(hidden_dim + encoder_dim, hidden_dim)
+        self.v = nn.Linear(hidden_dim, 1, bias=False)
+
+    def forward(self, hidden: torch.Tensor, encoder_outputs: torch.Tensor) -> torch.Tensor:
+        """hidden (B,1,H), encoder_outputs (B,S,E) -> context (B,1,E)."""
+        hidden = _lib.require_gpu(hidden, "hidden")
+        enc = _lib.require_gpu(encoder_outputs, "encoder_outputs")
+        B, S, E = enc.shape
+        if hidden.shape != (B, 1, self.hidden_dim) or E != self.encoder_dim:
+            raise RuntimeError(f"Attention: bad shapes hidden {tuple(hidden.shape)} enc {tuple(enc.shape)}")
+        ctx = torch.empty((B, 1, E), dtype=torch.float32, device=enc.device)
+        _lib.check(_lib.lib().i2l_attention_context_fwd(
+            hidden.data_ptr(), enc.data_ptr(), self.attn.weight.detach().contiguous().data_ptr(),
+            self.attn.bias.detach().data_ptr(), self.v.weight.detach().contiguous().data_ptr(), ctx.data_ptr(),
+            B, S, self.hidden_dim, E, _lib.stream_ptr()), "attention_context_fwd")
+        return ctx
+
+
+class LSTMDecoder(nn.Module):
+    """decoder.py:16-284.
+
+    Attention note: the encoder emits ONE vector per image, so Attention runs over a
+    source of length 1: softmax over one element is exactly 1.0 and
+    ``context == encoder_output`` bit-for-bit (decoder.py:338-341; golden fixture G7).
+    The step kernels therefore consume ``encoder_output`` directly for both
+    ``attention=True`` and ``attention=False``; results are identical to the reference's.
+    """
+
+    def __init__(self, vocab_size: int, embedding_dim: int = None, hidden_dim: int = None,
+                 max_seq_length: int = None, lstm_layers: int = None, dropout: float = None,
+                 attention: bool = True):
+        super().__init__()
+        # defaults of decoder.py:49-58
+        embedding_dim = 256 if embedding_dim is None else embedding_dim
+        hidden_dim = 256 if hidden_dim is None else hidden_dim
+        max_seq_length = 141 if max_seq_length is None else max_seq_length
+        lstm_layers = 1 if lstm_layers is None else lstm_layers
+        dropout = 0.1 if dropout is None else dropout
+        self.vocab_size, self.embedding_dim, self.hidden_dim = vocab_size, embedding_dim, hidden_dim
+        self.max_seq_length, self.lstm_layers, self.dropout = max_seq_length, lstm_layers, dropout
+        self.use_attention = attention
+        # creation order = the reference's (decoder.py:69-93) so torch.manual_seed gives the same init
+        self.embedding = nn.Embedding(vocab_size, embedding_dim)
+        self.lstm = nn.LSTM(input_size=2 * embedding_dim, hidden_size=hidden_dim, num_layers=lstm_layers,
+                            batch_first=True, dropout=dropout if lstm_layers > 1 else 0)
+        if attention:
+            self.attention = Attention(hidden_dim, embedding_dim)
+        self.output_layer = nn.Linear(hidden_dim, vocab_size)
+        self.dropout_layer = nn.Dropout(dropout)
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key = None          # (rows, weight versions) the weight images in _ws were built for
+
+    # ------------------------------------------------------------------ plumbing
+    def _weights_struct(self):
+        """(struct, keep-alive list) describing the parameters for the C ABI."""
+        L = self.lstm_layers
+        names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+        tens = {n: [_lib.require_gpu(getattr(self.lstm, f"{n}_l{l}").detach(), f"lstm.{n}_l{l}") for l in range(L)]
+                for n in names}
+        emb = _lib.require_gpu(self.embedding.weight.detach(), "embedding.weight")
+        wout = _lib.require_gpu(self.output_layer.weight.detach(), "output_layer.weight")
+        bout = _lib.require_gpu(self.output_layer.bias.detach(), "output_layer.bias")
+        arrs = {n: _lib.pointer_array(tens[n]) for n in names}
+        w = _lib.DecoderWeights()
+        w.embedding = emb.data_ptr()
+        w.w_ih, w.w_hh = arrs["weight_ih"], arrs["weight_hh"]
+        w.b_ih, w.b_hh = arrs["bias_ih"], arrs["bias_hh"]
+        w.w_out, w.b_out = wout.data_ptr(), bout.data_ptr()
+        w.vocab, w.embed, w.hidden, w.layers = self.vocab_size, self.embedding_dim, self.hidden_dim, L
+        return w, (tens, emb, wout, bout, arrs)
+
+    def _weights_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def prepare(self, encoder_output: torch.Tensor, reuse_weight_images: bool = False):
+        """Build the decode workspace for these encoder rows (i2l_decoder_prepare).
+        ``reuse_weight_images`` skips the weight re-layout when no parameter changed since
+        the last call (used by decode_step loops); the search entry points rebuild everything."""
+        enc = _lib.require_gpu(encoder_output, "encoder_output")
+        if enc.dim() != 2 or enc.shape[1] != self.embedding_dim:
+            raise RuntimeError(f"encoder_output must be (B,{self.embedding_dim}), got {tuple(enc.shape)}")
+        rows = enc.shape[0]
+        L = _lib.lib()
+        w, keep = self._weights_struct()
+        nbytes = L.i2l_decoder_workspace_bytes(rows, self.vocab_size, self.embedding_dim, self.hidden_dim,
+                                               self.lstm_layers)
+        if nbytes == 0:
+            raise RuntimeError("img2latex_amd: decoder dimensions not supported by the HIP kernels")
+        key = (rows, enc.device, self._weights_version())
+        what = _lib.PREP_ALL
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != enc.device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+            self._ws_key = None
+        if reuse_weight_images and self._ws_key == key:
+            what = _lib.PREP_ROWS
+        _lib.check(L.i2l_decoder_prepare(ctypes.byref(w), enc.data_ptr(), rows, what, self._ws.data_ptr(),
+                                         self._ws.numel(), _lib.stream_ptr()), "decoder_prepare")
+        self._ws_key = key
+        return w, keep, enc
+
+    def run_steps(self, encoder_output: torch.Tensor, steps: int, tok0: torch.Tensor,
+                  forced: Optional[torch.Tensor] = None, hidden: Optional[Hidden] = None,
+                  temperature: float = 1.0, select: int = _lib.SELECT_LOGITS, stop: int = _lib.STOP_NONE,
+                  end_id: int = -1, want_ids: bool = True, want_logits: bool = False,
+                  want_state: bool = False, reuse_weight_images: bool = False):
+        """prepare + one persistent i2l_greedy_decode launch.  Returns (ids, logits, (h, c))."""
+        w, keep, enc = self.prepare(encoder_output, reuse_weight_images)
+        rows, dev = enc.shape[0], enc.device
+        tok0 = _lib.require_gpu(tok0, "tok0", torch.int32)
+        if forced is not None:
+            forced = _lib.require_gpu(forced, "forced", torch.int32)
+            if forced.shape != (rows, steps):
+                raise RuntimeError(f"forced tokens must be ({rows},{steps}), got {tuple(forced.shape)}")
+        h0 = c0 = None
+        if hidden is not None:
+            h0 = _lib.require_gpu(hidden[0], "h0")
+            c0 = _lib.require_gpu(hidden[1], "c0")
+            shp = (self.lstm_layers, rows, self.hidden_dim)
+            if tuple(h0.shape) != shp or tuple(c0.shape) != shp:
+                raise RuntimeError(f"hidden state must be {shp}, got {tuple(h0.shape)} / {tuple(c0.shape)}")
+        ids = torch.empty((rows, steps), dtype=torch.int32, device=dev) if want_ids else None
+        logits = torch.empty((rows, steps, self.vocab_size), dtype=torch.float32, device=dev) if want_logits else None
+        h = c = None
+        if want_state:
+            h = torch.empty((self.lstm_layers, rows, self.hidden_dim), dtype=torch.float32, device=dev)
+            c = torch.empty_like(h)
+        _lib.check(_lib.lib().i2l_greedy_decode(
+            ctypes.byref(w), self._ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(forced), _lib.ptr(h0),
+            _lib.ptr(c0), float(temperature), select, stop, int(end_id), _lib.ptr(ids), _lib.ptr(logits),
+            _lib.ptr(h), _lib.ptr(c), _lib.stream_ptr()), "greedy_decode")
+        del keep
+        return ids, logits, ((h, c) if want_state else None)
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, encoder_output: torch.Tensor, target_sequence: torch.Tensor, hidden=None) -> torch.Tensor:
+        """Teacher forcing (decoder.py:100-195): (B,E), (B,T) int64 -> logits (B,T,V).
+        Inference/eval semantics (dropout is identity); the training path with backward
+        is the training-step entry point."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("img2latex_amd: decoder backward is not built yet (use eval()/no_grad())")
+        tgt = target_sequence
+        if not tgt.is_cuda:
+            raise RuntimeError("img2latex_amd: target_sequence must be on the ROCm device (no CPU fallback)")
+        B, T = tgt.shape
+        forced = tgt.to(torch.int32).contiguous()
+        _, logits, _ = self.run_steps(encoder_output, T, forced[:, 0].contiguous(), forced=forced, hidden=hidden,
+                                      want_ids=False, want_logits=True)
+        return logits
+
+    def decode_step(self, encoder_output: torch.Tensor, input_token: torch.Tensor, hidden=None
+                    ) -> Tuple[torch.Tensor, Hidden]:
+        """One step (decoder.py:197-284): (B,E), (B,1) int64, (h,c)|None -> (logits (B,1,V), (h,c)).
+        Returns fresh state tensors and never mutates its inputs (seq2seq.py:272 relies on it)."""
+        if input_token.dim() != 2 or input_token.shape[1] != 1:
+            raise RuntimeError(f"Shape mismatch: input_token must be (B,1), got {tuple(input_token.shape)}")
+        if not input_token.is_cuda:
+            raise RuntimeError("img2latex_amd: input_token must be on the ROCm device (no CPU fallback)")
+        tok0 = input_token.reshape(-1).to(torch.int32).contiguous()
+        _, logits, state = self.run_steps(encoder_output, 1, tok0, hidden=hidden, want_ids=False,
+                                          want_logits=True, want_state=True, reuse_weight_images=True)
+        return logits, state

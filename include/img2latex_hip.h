@@ -1,0 +1,152 @@
+/*
+ * img2latex_hip.h -- C ABI of libimg2latex_hip.so (MI355X / gfx950, HIP).
+ *
+ * The reference (Jeremy-Cleland/hmer-img2latex) has no FFI: its hot path is
+ * the Python class surface of img2latex.model calling ATen through torch.nn.
+ * Each entry point below replaces the ATen work of the cited reference lines;
+ * hmer-img2latex_amd/img2latex_amd/model/ binds them with ctypes and
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions:
+ *   - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer
+ *     into a caller-owned, contiguous, 16-byte-aligned fp32/int32 buffer unless
+ *     the parameter is documented as a HOST array of device pointers.
+ *   - explicit stream (a hipStream_t passed as void*; NULL = default stream);
+ *     every call only ENQUEUES work, it never synchronises or allocates.
+ *   - workspace is caller-provided; its size comes from *_workspace_bytes().
+ *   - return value: I2L_OK (0) or a negative I2L_ERR_* code; never throws,
+ *     never aborts; no global state (thread-compatible).
+ *   - tensors are row-major with the reference's (PyTorch) shapes.
+ */
+#ifndef IMG2LATEX_HIP_H
+#define IMG2LATEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2L_OK 0
+#define I2L_ERR_ARG (-1)          /* null pointer / non-positive dimension           */
+#define I2L_ERR_UNSUPPORTED (-2)  /* dimension outside what the kernels are built for */
+#define I2L_ERR_WORKSPACE (-3)    /* workspace missing or too small                   */
+#define I2L_ERR_LAUNCH (-4)       /* HIP reported a launch error                      */
+
+#define I2L_MAX_LSTM_LAYERS 4
+#define I2L_MAX_BEAM 8
+
+typedef void* i2l_stream_t;
+
+int i2l_version(void);
+const char* i2l_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * Encoder (reference img2latex/model/encoder.py)
+ * ---------------------------------------------------------------------- */
+
+/* One CNN block: y = maxpool2x2(relu(conv3x3_pad1(x, w) + bias)), floor pooling.
+ * Replaces nn.Conv2d + nn.ReLU + nn.MaxPool2d, encoder.py:78-95 executed at :122.
+ * x (B,Cin,H,W)  w (Cout,Cin,3,3)  bias (Cout)  y (B,Cout,H/2,W/2), NCHW fp32. */
+int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias, float* y,
+                               int B, int Cin, int H, int W, int Cout, i2l_stream_t stream);
+
+/* y = act(x @ w^T + bias): nn.Flatten + nn.Linear + nn.ReLU, encoder.py:105-107,125-127
+ * (also nn.Linear(Hd->V), decoder.py:90).  x (M,K)  w (N,K)  bias (N) or NULL  y (M,N).
+ * relu != 0 applies ReLU.  Split-K partials live in the workspace. */
+size_t i2l_linear_workspace_bytes(int M, int K, int N);
+int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, float* y,
+                            int M, int K, int N, int relu, void* workspace, size_t workspace_bytes,
+                            i2l_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Decoder (reference img2latex/model/decoder.py, seq2seq.py, predictor.py)
+ * ---------------------------------------------------------------------- */
+
+/* Weights of LSTMDecoder as the reference's state_dict holds them (decoder.py:69-90).
+ * w_ih/w_hh/b_ih/b_hh are HOST arrays of `layers` device pointers:
+ *   w_ih[0] (4H, 2E), w_ih[l>0] (4H, H), w_hh[l] (4H, H), b_ih[l], b_hh[l] (4H); gate order i,f,g,o. */
+typedef struct i2l_decoder_weights {
+    const float* embedding;      /* (V, E)  decoder.embedding.weight     */
+    const float* const* w_ih;    /* decoder.lstm.weight_ih_l{l}          */
+    const float* const* w_hh;    /* decoder.lstm.weight_hh_l{l}          */
+    const float* const* b_ih;    /* decoder.lstm.bias_ih_l{l}            */
+    const float* const* b_hh;    /* decoder.lstm.bias_hh_l{l}            */
+    const float* w_out;          /* (V, H)  decoder.output_layer.weight  */
+    const float* b_out;          /* (V)     decoder.output_layer.bias    */
+    int vocab, embed, hidden, layers;
+} i2l_decoder_weights;
+
+/* Bytes of workspace i2l_decoder_prepare() fills for a batch of `rows` encoder rows. */
+size_t i2l_decoder_workspace_bytes(int rows, int vocab, int embed, int hidden, int layers);
+
+/* Re-lay the decoder weights for the step kernels (gate-interleaved transposes),
+ * fold the token-side half of W_ih_l0 into a (V,4H) table, and compute the per-row
+ * constant  enc @ W_ih_l0[:, E:]^T + b_ih_l0 + b_hh_l0  (the half of the layer-0 gate
+ * GEMM that does not change over the decode loop; cat([emb, enc]) at decoder.py:228,274).
+ * With the reference's Attention over a length-1 source the context equals enc
+ * bit-for-bit (decoder.py:338-341, softmax over one element), so `enc` serves both the
+ * attention and the no-attention decoder.  enc (rows, E).  `what` selects the part to
+ * (re)build: the weight images must be rebuilt whenever a weight changes, the row part
+ * whenever enc changes; everything it writes is in `workspace`. */
+#define I2L_PREP_WEIGHTS 1   /* transposes + token table: depends on the weights only          */
+#define I2L_PREP_ROWS 2      /* per-row constant: depends on enc (and W_ih_l0, biases)        */
+#define I2L_PREP_ALL 3
+int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* enc, int rows, int what,
+                        void* workspace, size_t workspace_bytes, i2l_stream_t stream);
+
+/* Stop rules of the two greedy loops of the reference. */
+#define I2L_STOP_NONE 0    /* run all `steps`; Seq2SeqModel._greedy_search stops only when ALL
+                              rows emit END in one step (seq2seq.py:220) -- the host finds that
+                              step in the returned ids                                          */
+#define I2L_STOP_STICKY 1  /* Predictor.predict_batch: a row is finished after its first END
+                              (predictor.py:343); a row's ids after its END are -1              */
+
+/* Token selection. */
+#define I2L_SELECT_LOGITS 0   /* argmax(logits / temperature)           seq2seq.py:213-215      */
+#define I2L_SELECT_SOFTMAX 1  /* argmax(softmax(logits / temperature))  predictor.py:295-297,333 */
+
+/* The decode loop: `steps` iterations of [embedding lookup, LSTM step (all layers),
+ * output projection, token selection], one persistent launch, no host sync inside.
+ * Replaces the loops at seq2seq.py:210-221 and predictor.py:283-347 and, with
+ * steps == 1, LSTMDecoder.decode_step (decoder.py:197-284).
+ *   workspace   filled by i2l_decoder_prepare() for these `rows`
+ *   tok0        (rows) int32 first input token of every row
+ *   forced      (rows, steps) int32 or NULL; if given, the input token of step t is
+ *               forced[r][t] (teacher forcing) instead of the previous selection
+ *   h0, c0      (L, rows, H) or NULL (zeros, decoder.py:231-244)
+ *   ids_out     (rows, steps) int32 or NULL   selected token per step
+ *   logits_out  (rows, steps, V) or NULL      raw logits (before temperature)
+ *   h_out,c_out (L, rows, H) or NULL          state after the last executed step
+ * First index wins ties, as torch.argmax. */
+int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
+                      const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
+                      float temperature, int select, int stop, int end_id,
+                      int32_t* ids_out, float* logits_out, float* h_out, float* c_out,
+                      i2l_stream_t stream);
+
+/* Beam search for `images` independent images, `beam` beams each (<= I2L_MAX_BEAM):
+ * per image exactly Seq2SeqModel._beam_search at batch 1 (seq2seq.py:234-298) --
+ * log_softmax in fp32, top-k sorted descending with lower index first on ties, scores
+ * accumulated in fp64, stable descending selection, ended beams retire one iteration
+ * later, no length normalisation.  workspace prepared for rows == images.
+ *   seq_out  (images, steps+1) int32: best sequence, START stripped, cut at END, -1 padded
+ *   len_out  (images) int32;  score_out (images) fp64 or NULL. */
+size_t i2l_beam_workspace_bytes(int images, int beam, int hidden, int layers, int steps);
+int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspace, int images, int beam,
+                    int steps, int start_id, int end_id, void* beam_workspace,
+                    size_t beam_workspace_bytes, int32_t* seq_out, int32_t* len_out,
+                    double* score_out, i2l_stream_t stream);
+
+/* Additive attention, general source length S (Attention.forward, decoder.py:312-343):
+ * context[b] = softmax_s(v . tanh(W [hidden[b] ; enc[b,s]] + b_a)) @ enc[b].
+ * hidden (B,H)  enc (B,S,E)  w_attn (H, H+E)  b_attn (H)  v (H)  context (B,E). */
+int i2l_attention_context_fwd(const float* hidden, const float* enc, const float* w_attn,
+                              const float* b_attn, const float* v, float* context,
+                              int B, int S, int H, int E, i2l_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMG2LATEX_HIP_H */

@@ -1,0 +1,90 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/*.h declares,
+the host classes keep the reference's surface, and the product path refuses CPU tensors."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+from img2latex_amd import _lib, synth
+from img2latex_amd.model import Attention, CNNEncoder, LSTMDecoder, Seq2SeqModel
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "img2latex_hip.h")).read()
+    declared = set(re.findall(r"\b(i2l_[a-z0-9_]+)\s*\(", header))
+    declared -= {"i2l_stream_t"}
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    handle = _lib.lib()                       # binds every symbol, AttributeError if one is missing
+    assert handle.i2l_version() >= 100
+    assert handle.i2l_error_string(-2).decode().startswith("dimension")
+    # size queries are pure host code: callable without a GPU
+    assert handle.i2l_decoder_workspace_bytes(256, 512, 256, 256, 1) > 0
+    assert handle.i2l_decoder_workspace_bytes(0, 512, 256, 256, 1) == 0
+    assert handle.i2l_linear_workspace_bytes(256, 40960, 256) > 0
+
+
+def test_state_dict_keys_match_reference():
+    cfg = synth.model_config(lstm_layers=2, attention=True, embedding_dim=32, hidden_dim=64, vocab_size=50,
+                             channels=1, img_height=16, img_width=32, conv_filters=(4, 8, 16))
+    m = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+    ours = list(m.state_dict().keys())
+    want = list(synth.make_state_dict(cfg).keys())
+    assert sorted(ours) == sorted(want)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}, strict=True)
+
+
+def test_default_init_matches_reference_under_same_seed():
+    d = np.load(os.path.join(GOLDEN, "init_parity.npz"))
+    cfg = json.loads(str(d["cfg_json"]))
+    torch.manual_seed(1234)
+    m = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+    names = json.loads(str(d["names"]))
+    sd = m.state_dict()
+    assert list(sd.keys()) == names
+    got = np.array([synth.checksum(sd[k].numpy()) for k in names])
+    np.testing.assert_allclose(got, d["checksums"], rtol=0, atol=0)
+
+
+def test_constructor_defaults_and_errors():
+    enc = CNNEncoder()
+    assert (enc.img_height, enc.img_width, enc.channels, enc.embedding_dim) == (64, 800, 1, 256)   # encoder.py:51-64
+    assert enc.embedding_layer.in_features == 128 * 8 * 100
+    dec = LSTMDecoder(vocab_size=10)
+    assert (dec.embedding_dim, dec.hidden_dim, dec.max_seq_length, dec.lstm_layers, dec.dropout) == (256, 256, 141, 1, 0.1)
+    assert dec.use_attention and isinstance(dec.attention, Attention)                                # decoder.py:32
+    m = Seq2SeqModel()
+    assert m.vocab_size == 100 and not m.decoder.use_attention                                       # seq2seq.py:51,90
+    assert m.encoder.embedding_layer.in_features == 128 * (50 // 8) * (200 // 8)
+    with pytest.raises(ValueError):
+        Seq2SeqModel(model_type="transformer")
+    with pytest.raises(NotImplementedError):
+        CNNEncoder(kernel_size=5)
+
+
+def test_no_cpu_fallback():
+    cfg = synth.model_config(embedding_dim=32, hidden_dim=64, vocab_size=50, channels=1, img_height=16,
+                             img_width=32, conv_filters=(4, 8, 16))
+    m = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg)).eval()
+    x = torch.zeros(2, 1, 16, 32)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.encoder(x)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.decoder.decode_step(torch.zeros(2, 32), torch.ones(2, 1, dtype=torch.long), None)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.inference(x, 1, 2, max_length=4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "hmer-img2latex_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "img2latex_oracle" not in src and "import oracle" not in src, f

@@ -1,0 +1,218 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures generated from the real reference.  Tolerances: token ids exact; encoder / state
+1e-5, logits 1e-4 (BASELINE.json north_star), relative to max(1,|ref|)."""
+import numpy as np
+import pytest
+import torch
+
+import img2latex_oracle as O
+from helpers import ALL, END, SMALL, START, images, load, padded_to_lists, sample, torch_state_dict
+from img2latex_amd import _lib, synth
+from img2latex_amd.model import Seq2SeqModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(a, b, tol):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f"max err {err} > {tol} * {scale}"
+
+
+_MODELS = {}
+
+
+def model_for(name, sd_kw=None, cfg=None):
+    key = (name, repr(sd_kw))
+    if key not in _MODELS:
+        if cfg is None:
+            _, cfg, kw = load(name)
+            sd_kw = kw if sd_kw is None else sd_kw
+        m = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg, **sd_kw).items()})
+        _MODELS[key] = (m.to(DEV).eval(), cfg)
+    return _MODELS[key]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_encoder_vs_golden(name):
+    d, cfg, _ = load(name)
+    m, _ = model_for(name)
+    x = images(cfg, device=DEV)
+    with torch.no_grad():
+        blocks = m.encoder.conv_blocks(x)
+        enc = m.encoder(x)
+    for i, b in enumerate(blocks):
+        assert list(b.shape) == list(d[f"g1_block{i}_shape"])
+        if f"g1_block{i}" in d:
+            close(b.cpu().numpy(), d[f"g1_block{i}"], 1e-5)
+        else:
+            close(sample(b), d[f"g1_block{i}_sample"], 1e-5)
+    close(enc.cpu().numpy(), d["g1_enc"], 1e-5)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_decode_step_vs_golden(name):
+    d, cfg, _ = load(name)
+    m, _ = model_for(name)
+    enc = torch.from_numpy(d["g1_enc"]).to(DEV)
+    tok = torch.full((4, 1), START, dtype=torch.long, device=DEV)
+    hidden = None
+    with torch.no_grad():
+        for s in range(3):
+            prev = None if hidden is None else (hidden[0].clone(), hidden[1].clone())
+            logits, new_hidden = m.decoder.decode_step(enc, tok, hidden)
+            if prev is not None:                     # inputs are never mutated (seq2seq.py:272 relies on it)
+                assert torch.equal(prev[0], hidden[0]) and torch.equal(prev[1], hidden[1])
+            hidden = new_hidden
+            assert logits.shape == (4, 1, cfg["vocab_size"])
+            close(logits.cpu().numpy(), d[f"g2_logits{s}"], 1e-4)
+            close(hidden[0].cpu().numpy(), d[f"g2_h{s}"], 1e-5)
+            close(hidden[1].cpu().numpy(), d[f"g2_c{s}"], 1e-5)
+            tok = logits.squeeze(1).argmax(-1, keepdim=True)
+            assert np.array_equal(tok.cpu().numpy(), d[f"g2_tok{s}"])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_greedy_ids_vs_golden(name):
+    d, cfg, _ = load(name)
+    m, _ = model_for(name)
+    x = images(cfg, device=DEV)
+    with torch.no_grad():
+        ids = m.inference(x, START, END, max_length=32)
+        one = m.inference(x[1:2], START, END, max_length=32)
+        idt = m.inference(x, START, END, max_length=12, temperature=0.7)
+        fb = m.inference(x, START, END, max_length=10, beam_size=3)          # batch > 1: greedy fallback
+    assert np.array_equal(np.array(ids), d["g3_b4_ids"])
+    assert list(one) == list(d["g3_b1_ids"])
+    assert np.array_equal(np.array(idt), d["g3_b4_temp_ids"])
+    assert np.array_equal(np.array(fb), d["g4_fallback_ids"])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_teacher_forced_logits_vs_golden(name):
+    d, cfg, _ = load(name)
+    m, _ = model_for(name)
+    big = name in ("primary", "secondary")
+    T = 24 if big else 12
+    forms = torch.from_numpy(synth.make_formulas(4, T, cfg["vocab_size"], seed=777, min_len=5)).to(DEV)
+    with torch.no_grad():
+        logits = m(images(cfg, device=DEV), forms)
+    assert logits.shape == (4, T - 1, cfg["vocab_size"])
+    if "g6_logits" in d:
+        close(logits.cpu().numpy(), d["g6_logits"], 1e-4)
+    else:
+        close(sample(logits), d["g6_logits_sample"], 1e-4)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_sticky_stop_loop_vs_golden(name):
+    """Predictor.predict_batch semantics (predictor.py:283-358)."""
+    d, cfg, _ = load(name)
+    m, _ = model_for(name)
+    with torch.no_grad():
+        enc = m.encoder(images(cfg, device=DEV))
+        ids, _ = m.greedy_ids(enc, START, END, 32, stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX)
+    rows = []
+    for r in ids.cpu().tolist():
+        r = [t for t in r if t >= 0]
+        rows.append(r[: r.index(END)] if END in r else r)
+    assert rows == padded_to_lists(d["g5_ids"], d["g5_len"])
+
+
+def _margin_guard(got, ref_ids, margins, tol):
+    """ids must agree with the reference up to the first step whose reference top1-top2
+    margin is below tol (a fp32 near-tie, after which sequences legitimately diverge)."""
+    diverged = 0
+    for b in range(ref_ids.shape[0]):
+        ne = np.nonzero(got[b] != ref_ids[b, 1:1 + got.shape[1]])[0]
+        if ne.size:
+            t = int(ne[0])
+            assert margins[b, t] < tol, f"row {b} step {t}: ids differ at margin {margins[b, t]}"
+            diverged += 1
+    return diverged
+
+
+@pytest.mark.parametrize("fname", ["primary_cfg2_clock", "primary_cfg2"])
+def test_cfg2_batch256_ids(fname):
+    """BASELINE config 2 at full size: B=256, up to 150 steps."""
+    d, cfg, sd_kw = load(fname)
+    m, _ = model_for(fname, sd_kw, cfg)
+    ref_ids = d["ids"].astype(np.int64)
+    steps = ref_ids.shape[1] - 1
+    x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(DEV)
+    with torch.no_grad():
+        enc = m.encoder(x)
+        ids, _ = m.greedy_ids(enc, START, END, 150)
+        seqs = m._greedy_search(enc, START, END, 150, 1.0, 0, 0.0)
+        # teacher-forced replay along the REFERENCE ids: every step is checked independently
+        forced = torch.from_numpy(ref_ids[:, :steps].astype(np.int32)).to(DEV)
+        _, logits, _ = m.decoder.run_steps(enc, steps, forced[:, 0].contiguous(), forced=forced,
+                                           want_ids=False, want_logits=True)
+    close(enc.reshape(-1)[:: 256 * cfg["embedding_dim"] // 1024][:1024].cpu().numpy(), d["enc_sample"], 1e-5)
+    assert len(seqs[0]) == steps + 1, "global stop step (all rows END in one step) differs"
+    got = ids.cpu().numpy()[:, :steps]
+    diverged = _margin_guard(got, ref_ids, d["margins"], tol=2e-4)
+    assert diverged <= 0.05 * 256
+    top = logits.argmax(-1).cpu().numpy()
+    wide = d["margins"] > 2e-4
+    assert np.array_equal(top[wide], ref_ids[:, 1:][wide])
+    top2 = torch.topk(logits, 2, dim=-1).values
+    close((top2[..., 0] - top2[..., 1]).cpu().numpy(), d["margins"], 1e-4)
+
+
+def test_linear_kernel_odd_shapes():
+    torch.manual_seed(0)
+    L = _lib.lib()
+    for (M, K, N, relu) in [(1, 7, 3, 0), (5, 33, 70, 1), (67, 130, 65, 1), (4, 4096, 33, 0), (256, 1024, 96, 1)]:
+        x, w, b = torch.randn(M, K), torch.randn(N, K) / K ** 0.5, torch.randn(N)
+        want = torch.nn.functional.linear(x, w, b)
+        want = want.relu() if relu else want
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        y = torch.empty(M, N, device=DEV)
+        nbytes = L.i2l_linear_workspace_bytes(M, K, N)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
+        rc = L.i2l_linear_bias_act_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, K, N, relu,
+                                       ws.data_ptr(), nbytes, _lib.stream_ptr())
+        assert rc == 0
+        close(y.cpu().numpy(), want.numpy(), 1e-5)
+
+
+def test_conv_kernel_odd_shapes():
+    torch.manual_seed(1)
+    L = _lib.lib()
+    for (B, Cin, H, W, Cout) in [(1, 1, 2, 2, 1), (2, 3, 7, 9, 5), (3, 5, 16, 70, 9), (2, 16, 33, 131, 24), (1, 64, 16, 80, 128)]:
+        x, w, b = torch.randn(B, Cin, H, W), torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5), torch.randn(Cout)
+        want = O.conv_block(x, w, b)
+        y = torch.empty(B, Cout, H // 2, W // 2, device=DEV)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)             # keep the device copies alive
+        rc = L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(),
+                                          y.data_ptr(), B, Cin, H, W, Cout, _lib.stream_ptr())
+        assert rc == 0
+        close(y.cpu().numpy(), want.numpy(), 1e-5)
+
+
+def test_error_codes_not_exceptions():
+    L = _lib.lib()
+    assert L.i2l_conv3x3_relu_pool2_fwd(None, None, None, None, 1, 1, 4, 4, 1, None) == -1
+    assert L.i2l_linear_bias_act_fwd(None, None, None, None, 1, 1, 1, 0, None, 0, None) == -1
+
+
+def test_rows_are_independent_and_batch_tail():
+    """Ragged batch sizes: B not a multiple of the rows-per-workgroup tiling; row b of a
+    batch must equal the same image decoded alone."""
+    d, cfg, _ = load("tiny_l2_attn")
+    m, _ = model_for("tiny_l2_attn")
+    x = images(cfg, batch=7, seed=99, device=DEV)
+    with torch.no_grad():
+        enc = m.encoder(x)
+        ids7, _ = m.greedy_ids(enc, START, END, 20)
+        ids1, _ = m.greedy_ids(enc[3:4].contiguous(), START, END, 20)
+        big = enc.repeat(90, 1).contiguous()                     # 630 rows -> 4 rows per workgroup, ragged tail
+        idsb, _ = m.greedy_ids(big, START, END, 20)
+    assert torch.equal(ids7[3], ids1[0])
+    assert torch.equal(idsb[: 7], ids7) and torch.equal(idsb[623:630], ids7)
