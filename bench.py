@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decoded LaTeX tokens/s, CNN-LSTM greedy decode, batch 256 per GPU,
+320x64x3 synthetic images, 150 decode steps (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch already resident in HBM:
+3 fused conv blocks -> Flatten+Linear+ReLU -> decoder prepare -> persistent greedy decode
+loop of 150 steps -> token ids copied to (pinned) host memory.  Inference shards with no
+collective (images are independent), so N GPUs run N replicas on different batches
+("scaling": "weak"); value = all ranks' tokens / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the driver's keys plus "roofline" (dominant kernel,
+timed live with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on
+this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "hmer-img2latex_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from img2latex_amd import _lib, synth  # noqa: E402
+from img2latex_amd.model import Seq2SeqModel  # noqa: E402
+
+# MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+PEAK_FP32_TFLOPS = 157.3          # fp32 MFMA = fp32 vector peak
+
+
+def stage_costs(cfg, B, steps):
+    """Algorithmic flops / bytes per launch, keyed by stage mark."""
+    out = {}
+    cin, h, w = cfg["channels"], cfg["img_height"], cfg["img_width"]
+    for i, cout in enumerate(cfg["conv_filters"]):
+        flops = 2.0 * 9 * cin * cout * h * w * B
+        byts = 4.0 * (B * cin * h * w + B * cout * (h // 2) * (w // 2) + cout * cin * 9 + cout)
+        out[f"conv{i}"] = dict(flops=flops, bytes=byts)
+        cin, h, w = cout, h // 2, w // 2
+    K, E, H, V = cin * h * w, cfg["embedding_dim"], cfg["hidden_dim"], cfg["vocab_size"]
+    out["fc"] = dict(flops=2.0 * B * K * E, bytes=4.0 * (B * K + E * K + B * E + E))
+    L = cfg["lstm_layers"]
+    per_tok = 2.0 * (4 * H * (2 * E + H) + (L - 1) * 4 * H * 2 * H + H * V)      # 1.835 MFLOP at primary dims
+    wbytes = 4.0 * (4 * H * H * (2 * L - 1) + H * V + V * 4 * H)                 # images streamed per step
+    out["decode"] = dict(flops=per_tok * B * steps, bytes=wbytes * steps)
+    out["prepare"] = dict(flops=2.0 * (V + B) * E * 4 * H, bytes=4.0 * (V * E + 4 * H * 2 * E + (V + B) * 4 * H))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--seq", type=int, default=150, help="decode steps (max_length)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, T = args.batch, args.seq
+    cfg = synth.model_config()                                        # primary dims: E=Hd=256, L=1, V=512, 3x64x320
+    sd_kw = dict(seed=42, out_scale=8.0, enc_scale=16.0)              # = tests/golden/primary_cfg2 weights
+    model = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, **sd_kw).items()})
+    model = model.to(dev).eval()
+    images = torch.from_numpy(synth.make_images(B, cfg, seed=1234 + rank)).to(dev)   # resident in HBM
+    ids_host = torch.empty((B, T), dtype=torch.int32).pin_memory()
+
+    events = []                                                       # (name, event) on the launch stream
+
+    def hook(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        events.append((name, ev))
+
+    def one_step():
+        with torch.no_grad():
+            enc = model.encoder(images)
+            ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
+            ids_host.copy_(ids, non_blocking=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    _lib.set_stage_hook(hook)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    _lib.set_stage_hook(None)
+
+    # steps actually executed by the reference's stop rule (all rows END in one step, seq2seq.py:220)
+    all_end = (ids_host == synth.END).all(dim=0)
+    executed = int(all_end.nonzero()[0]) + 1 if bool(all_end.any()) else T
+    tokens_per_step = B * executed
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tok = torch.tensor([tokens_per_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(tok, op=dist.ReduceOp.SUM)
+        total_tokens_per_step = float(tok.item())
+    else:
+        total_tokens_per_step = float(tokens_per_step)
+
+    # per-stage device time from the HIP events recorded inside the timed region
+    stage_ms = {}
+    for (n0, e0), (n1, e1) in zip(events[:-1], events[1:]):
+        if n1 == "begin":
+            continue
+        stage_ms.setdefault(n1, []).append(e0.elapsed_time(e1))
+    stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+    costs = stage_costs(cfg, B, executed)
+    stages = []
+    for name, ms in stage_avg.items():
+        c = costs.get(name)
+        if c is None:
+            continue
+        stages.append(dict(kernel=name, ms=round(ms, 4), tflops=round(c["flops"] / ms / 1e9, 3),
+                           gbs=round(c["bytes"] / ms / 1e6, 2),
+                           frac_fp32=round(c["flops"] / ms / 1e9 / PEAK_FP32_TFLOPS, 4),
+                           frac_hbm=round(c["bytes"] / ms / 1e6 / PEAK_HBM_GBS, 4)))
+    dom = max(stages, key=lambda s: s["ms"])
+    # every stage of this path is arithmetic-bound at these shapes (conv AI 39..384 FLOP/B, decode weights are
+    # L2-resident): the roofline is the fp32 matrix/vector peak; the HBM view of each stage is in "stages".
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom["kernel"])
+    roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=dom["tflops"], peak=PEAK_FP32_TFLOPS,
+                    unit="TFLOP/s", frac=round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), traffic=traffic,
+                    launch_ms=dom["ms"], stages=stages)
+
+    result = {
+        "metric": "decoded LaTeX tokens/sec at batch 256, 320x64 imgs, seq 150",
+        "value": round(total_tokens_per_step * args.steps / elapsed, 1),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "cnn_lstm greedy decode (BASELINE configs[1])", "batch_per_gpu": B,
+                   "global_batch": B * world, "image": "3x64x320", "decode_steps": executed,
+                   "embedding_dim": cfg["embedding_dim"], "hidden_dim": cfg["hidden_dim"],
+                   "lstm_layers": cfg["lstm_layers"], "vocab": cfg["vocab_size"],
+                   "parallelism": f"replicas x{world} (no collective)"},
+        "roofline": roofline,
+    }
+
+    if rank == 0:
+        print(f"[bench] gpu: {result['value']:.0f} tokens/s, {result['ms_per_step']:.3f} ms/step", file=sys.stderr,
+              flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, sd_kw, B, T)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def host_cores():
+    """CPU share of this process: affinity mask, capped by the cgroup quota and by the GPU
+    box's documented share (16 cores per GPU) -- os.cpu_count() reports the whole host and
+    oversubscribing OpenMP by 10x stalls the oracle."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfg, sd_kw, B, T):
+    """The CPU oracle (id-exact restatement of the reference's PyTorch CPU path, pinned by
+    tests/golden) timed on this host's cores on the SAME workload: full batch, full 150 steps,
+    median of 3 runs (about 10-20 s of CPU work)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import img2latex_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
+    sd = O.to_torch_sd(synth.make_state_dict(cfg, **sd_kw))
+    x = torch.from_numpy(synth.make_images(B, cfg, seed=1234))
+    times, enc_t, steps = [], [], T
+    with torch.no_grad():
+        for _ in range(3):
+            t0 = time.perf_counter()
+            enc = O.cnn_encoder(sd, cfg, x)
+            t1 = time.perf_counter()
+            ids = O.greedy_search(sd, cfg, enc, synth.START, synth.END, T)
+            t2 = time.perf_counter()
+            steps = len(ids[0]) - 1
+            times.append(t2 - t0)
+            enc_t.append(t1 - t0)
+            print(f"[bench] cpu run {len(times)}: {t2 - t0:.2f} s", file=sys.stderr, flush=True)
+            if sum(times) > 30.0:
+                break
+    med = float(np.median(times))
+    return {"value": round(B * steps / med, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"full workload: B={B}, {steps} steps, median of {len(times)} (encoder {np.median(enc_t) * 1e3:.0f} ms of "
+                      f"{med * 1e3:.0f} ms), torch {torch.__version__} CPU fp32, {cores} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -100,3 +100,17 @@ def pointer_array(tensors: Sequence[torch.Tensor]):
     for i, t in enumerate(tensors):
         arr[i] = t.data_ptr()
     return arr
+
+
+# ---- optional stage marks (bench.py records a HIP event on the current stream at each mark)
+_STAGE_HOOK = None
+
+
+def set_stage_hook(fn) -> None:
+    global _STAGE_HOOK
+    _STAGE_HOOK = fn
+
+
+def mark(name: str) -> None:
+    if _STAGE_HOOK is not None:
+        _STAGE_HOOK(name)

@@ -67,6 +67,7 @@ class CNNEncoder(nn.Module):
             raise RuntimeError(f"expected (B,{self.channels},H,W) images, got {tuple(x.shape)}")
         L = _lib.lib()
         outs = []
+        _lib.mark("begin")
         for i in range(len(self.conv_filters)):
             conv = self.cnn_layers[3 * i]
             B, cin, h, w = x.shape
@@ -76,6 +77,7 @@ class CNNEncoder(nn.Module):
             _lib.check(L.i2l_conv3x3_relu_pool2_fwd(x.data_ptr(), wt.data_ptr(), bs.data_ptr(), y.data_ptr(),
                                                     B, cin, h, w, conv.out_channels, _lib.stream_ptr()),
                        "conv3x3_relu_pool2_fwd")
+            _lib.mark(f"conv{i}")
             outs.append(y)
             x = y
         return outs
@@ -98,4 +100,5 @@ class CNNEncoder(nn.Module):
         _lib.check(L.i2l_linear_bias_act_fwd(feat.data_ptr(), wt.data_ptr(), bs.data_ptr(), out.data_ptr(),
                                              B, K, E, 1, _lib.ptr(ws), nbytes, _lib.stream_ptr()),
                    "linear_bias_act_fwd")
+        _lib.mark("fc")
         return out

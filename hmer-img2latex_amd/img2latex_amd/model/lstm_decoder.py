@@ -126,6 +126,7 @@ class LSTMDecoder(nn.Module):
         _lib.check(L.i2l_decoder_prepare(ctypes.byref(w), enc.data_ptr(), rows, what, self._ws.data_ptr(),
                                          self._ws.numel(), _lib.stream_ptr()), "decoder_prepare")
         self._ws_key = key
+        _lib.mark("prepare")
         return w, keep, enc
 
     def run_steps(self, encoder_output: torch.Tensor, steps: int, tok0: torch.Tensor,
@@ -158,6 +159,7 @@ class LSTMDecoder(nn.Module):
             ctypes.byref(w), self._ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(forced), _lib.ptr(h0),
             _lib.ptr(c0), float(temperature), select, stop, int(end_id), _lib.ptr(ids), _lib.ptr(logits),
             _lib.ptr(h), _lib.ptr(c), _lib.stream_ptr()), "greedy_decode")
+        _lib.mark("decode")
         del keep
         return ids, logits, ((h, c) if want_state else None)
 
