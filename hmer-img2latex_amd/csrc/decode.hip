@@ -84,8 +84,8 @@ __global__ void bout_pad_kernel(const float* __restrict__ b_out, float* __restri
     if (v < Vp) out[v] = v < V ? b_out[v] : -INFINITY;
 }
 
-struct DecodeParams {
-    int B, H, L, V, Vp, T;
+struct StepWeights {
+    int H, L, V, Vp;
     const float* P;
     const float* Genc;
     const float* WhhT[MAXL];
@@ -93,6 +93,11 @@ struct DecodeParams {
     const float* biasP[MAXL];
     const float* WoutT;
     const float* boutP;
+};
+
+struct DecodeParams {
+    StepWeights w;
+    int B, T;
     const int32_t* tok0;
     const int32_t* forced;
     const float* h0;
@@ -168,11 +173,115 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// All L layers of one LSTM time step for R rows of one workgroup (decoder.py:247/277 at seq len 1).
+// h is double-buffered in LDS: reads hs[par], writes hs[par^1]; c_in -> c_out (may alias: each
+// element is read and written by the same thread).  tok[r] selects the row of P, grow[r] the row of Genc.
+// Ends with a __syncthreads(): hs[par^1] is complete on return.
+template <int R>
+__device__ __forceinline__ void lstm_layers(const StepWeights& w, const int (&tok)[R], const int (&grow)[R],
+                                            float* hs, const float* c_in, float* c_out, int par, int tid) {
+    const int H = w.H, L = w.L;
+    const size_t G = 4 * (size_t)H;
+    for (int l = 0; l < L; ++l) {
+        const float* h_old = hs + ((size_t)par * L + l) * R * H;
+        float* h_new = hs + ((size_t)(par ^ 1) * L + l) * R * H;
+        for (int j = tid; j < H; j += NT) {
+            float4 acc[R];
+            if (l == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 a = *reinterpret_cast<const float4*>(w.P + (size_t)tok[r] * G + 4 * j);
+                    const float4 e = *reinterpret_cast<const float4*>(w.Genc + (size_t)grow[r] * G + 4 * j);
+                    acc[r] = make_float4(a.x + e.x, a.y + e.y, a.z + e.z, a.w + e.w);
+                }
+            } else {
+                const float4 bb = *reinterpret_cast<const float4*>(w.biasP[l] + 4 * j);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = bb;
+                matvec4<R>(acc, w.WihT[l] + 4 * j, G, hs + ((size_t)(par ^ 1) * L + (l - 1)) * R * H, H);
+            }
+            matvec4<R>(acc, w.WhhT[l] + 4 * j, G, h_old, H);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const size_t ci = ((size_t)l * R + r) * H + j;
+                const float ig = sigmoidf_(acc[r].x), fg = sigmoidf_(acc[r].y);
+                const float gg = tanhf(acc[r].z), og = sigmoidf_(acc[r].w);
+                const float cn = fg * c_in[ci] + ig * gg;
+                c_out[ci] = cn;
+                h_new[r * H + j] = og * tanhf(cn);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// logits = h_top @ W_out^T + b for R rows; thread t owns columns 2t, 2t+1 (+512 per pass).
+// Optionally writes raw logits to global (lp[r] != null), keeps (logit / temperature) in LDS (lg != null),
+// and returns each thread's running (max, first index) over its columns.
+template <int R>
+__device__ __forceinline__ void project(const StepWeights& w, const float* h_top, float* const (&lp)[R],
+                                        float* lg, bool use_temp, float temperature, float (&best)[R],
+                                        int (&besti)[R], int tid) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best[r] = -INFINITY; besti[r] = 0x7fffffff; }
+    for (int v0 = 2 * tid; v0 < w.Vp; v0 += VCHUNK) {
+        float2 acc[R];
+        const float2 bb = *reinterpret_cast<const float2*>(w.boutP + v0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = bb;
+        matvec2<R>(acc, w.WoutT + v0, (size_t)w.Vp, h_top, w.H);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (lp[r]) {
+                if (v0 < w.V) lp[r][v0] = acc[r].x;
+                if (v0 + 1 < w.V) lp[r][v0 + 1] = acc[r].y;
+            }
+            float a = acc[r].x, b2 = acc[r].y;
+            if (use_temp) { a = a / temperature; b2 = b2 / temperature; }
+            if (lg) { lg[r * w.Vp + v0] = a; lg[r * w.Vp + v0 + 1] = b2; }
+            if (a > best[r]) { best[r] = a; besti[r] = v0; }
+            if (b2 > best[r]) { best[r] = b2; besti[r] = v0 + 1; }
+        }
+    }
+}
+
+// Fold per-thread (max, index) pairs over the workgroup; on return every thread holds the result.
+// redv/redi: LDS [NT/64][R].  Contains two __syncthreads().
+template <int R>
+__device__ __forceinline__ void block_argmax(float (&best)[R], int (&besti)[R], float* redv, int* redi, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        wave_argmax(best[r], besti[r]);
+        if (lane == 0) { redv[wave * R + r] = best[r]; redi[wave * R + r] = besti[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float bv = redv[r];
+        int bi = redi[r];
+#pragma unroll
+        for (int wv = 1; wv < NT / 64; ++wv) {
+            const float ov = redv[wv * R + r];
+            const int oi = redi[wv * R + r];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        best[r] = bv; besti[r] = bi;
+    }
+    __syncthreads();
+}
+
 template <int R>
 __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int H = p.H, L = p.L, B = p.B, T = p.T, V = p.V;
-    const size_t G = 4 * (size_t)H;
+    const StepWeights& w = p.w;
+    const int H = w.H, L = w.L, B = p.B, T = p.T, V = w.V;
     float* hs = smem;                          // [2][L][R][H]  double-buffered h
     float* cs = hs + 2 * L * R * H;            // [L][R][H]
     float* redv = cs + L * R * H;              // [4][R]
@@ -183,6 +292,9 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * R;
+    int grow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) grow[r] = min(row0 + r, B - 1);
 
     for (int idx = tid; idx < L * R * H; idx += NT) {
         const int l = idx / (R * H);
@@ -204,95 +316,28 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
         int tok[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int row = min(row0 + r, B - 1);
-            int tk = p.forced ? p.forced[(size_t)row * T + t] : tok_s[r];
+            int tk = p.forced ? p.forced[(size_t)grow[r] * T + t] : tok_s[r];
             tok[r] = min(max(tk, 0), V - 1);
         }
-        // ---------------- LSTM layers
-        for (int l = 0; l < L; ++l) {
-            const float* h_old = hs + ((size_t)par * L + l) * R * H;
-            float* h_new = hs + ((size_t)(par ^ 1) * L + l) * R * H;
-            for (int j = tid; j < H; j += NT) {
-                float4 acc[R];
-                if (l == 0) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int row = min(row0 + r, B - 1);
-                        const float4 a = *reinterpret_cast<const float4*>(p.P + (size_t)tok[r] * G + 4 * j);
-                        const float4 e = *reinterpret_cast<const float4*>(p.Genc + (size_t)row * G + 4 * j);
-                        acc[r] = make_float4(a.x + e.x, a.y + e.y, a.z + e.z, a.w + e.w);
-                    }
-                } else {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.biasP[l] + 4 * j);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r] = bb;
-                    matvec4<R>(acc, p.WihT[l] + 4 * j, G, hs + ((size_t)(par ^ 1) * L + (l - 1)) * R * H, H);
-                }
-                matvec4<R>(acc, p.WhhT[l] + 4 * j, G, h_old, H);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float* cp = cs + ((size_t)l * R + r) * H + j;
-                    const float ig = sigmoidf_(acc[r].x), fg = sigmoidf_(acc[r].y);
-                    const float gg = tanhf(acc[r].z), og = sigmoidf_(acc[r].w);
-                    const float cn = fg * (*cp) + ig * gg;
-                    *cp = cn;
-                    h_new[r * H + j] = og * tanhf(cn);
-                }
-            }
-            __syncthreads();
-        }
+        lstm_layers<R>(w, tok, grow, hs, cs, cs, par, tid);
+
         // ---------------- output projection + token selection
         const float* h_top = hs + ((size_t)(par ^ 1) * L + (L - 1)) * R * H;
+        float* lp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            lp[r] = (p.logits && row0 + r < B) ? p.logits + ((size_t)(row0 + r) * T + t) * V : nullptr;
         float best[R];
         int besti[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { best[r] = -INFINITY; besti[r] = 0x7fffffff; }
-        for (int v0 = 2 * tid; v0 < p.Vp; v0 += VCHUNK) {
-            float2 acc[R];
-            const float2 bb = *reinterpret_cast<const float2*>(p.boutP + v0);
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = bb;
-            matvec2<R>(acc, p.WoutT + v0, (size_t)p.Vp, h_top, H);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int row = row0 + r;
-                if (p.logits && row < B) {
-                    float* lp = p.logits + ((size_t)row * T + t) * V;
-                    if (v0 < V) lp[v0] = acc[r].x;
-                    if (v0 + 1 < V) lp[v0 + 1] = acc[r].y;
-                }
-                float a = acc[r].x, b2 = acc[r].y;
-                if (p.use_temp) { a = a / p.temperature; b2 = b2 / p.temperature; }
-                if (p.select == I2L_SELECT_SOFTMAX) { lg[r * p.Vp + v0] = a; lg[r * p.Vp + v0 + 1] = b2; }
-                if (a > best[r]) { best[r] = a; besti[r] = v0; }
-                if (b2 > best[r]) { best[r] = b2; besti[r] = v0 + 1; }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            wave_argmax(best[r], besti[r]);
-            if (lane == 0) { redv[wave * R + r] = best[r]; redi[wave * R + r] = besti[r]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {           // every thread folds the 4 wave results (same answer everywhere)
-            float bv = redv[r];
-            int bi = redi[r];
-#pragma unroll
-            for (int w = 1; w < NT / 64; ++w) {
-                const float ov = redv[w * R + r];
-                const int oi = redi[w * R + r];
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            best[r] = bv; besti[r] = bi;
-        }
+        project<R>(w, h_top, lp, p.select == I2L_SELECT_SOFTMAX ? lg : nullptr, p.use_temp != 0, p.temperature,
+                   best, besti, tid);
+        block_argmax<R>(best, besti, redv, redi, tid);
         if (p.select == I2L_SELECT_SOFTMAX) {
             // argmax(softmax(x)): probabilities in fp32 as torch.softmax (exp(x - max) / sum), first index wins
-            __syncthreads();                     // redv/redi are reused below
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float s = 0.f;
-                for (int v = tid; v < V; v += NT) s += expf(lg[r * p.Vp + v] - best[r]);
+                for (int v = tid; v < V; v += NT) s += expf(lg[r * w.Vp + v] - best[r]);
                 s = wave_sum(s);
                 if (lane == 0) redv[wave * R + r] = s;
             }
@@ -303,34 +348,18 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
             for (int r = 0; r < R; ++r) {
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NT / 64; ++w) s += redv[w * R + r];
+                for (int wv = 0; wv < NT / 64; ++wv) s += redv[wv * R + r];
                 pbest[r] = -1.f; pbesti[r] = 0x7fffffff;
                 for (int v = tid; v < V; v += NT) {
-                    const float pr = expf(lg[r * p.Vp + v] - best[r]) / s;
+                    const float pr = expf(lg[r * w.Vp + v] - best[r]) / s;
                     if (pr > pbest[r]) { pbest[r] = pr; pbesti[r] = v; }
                 }
             }
             __syncthreads();
+            block_argmax<R>(pbest, pbesti, redv, redi, tid);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                wave_argmax(pbest[r], pbesti[r]);
-                if (lane == 0) { redv[wave * R + r] = pbest[r]; redi[wave * R + r] = pbesti[r]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float bv = redv[r];
-                int bi = redi[r];
-#pragma unroll
-                for (int w = 1; w < NT / 64; ++w) {
-                    const float ov = redv[w * R + r];
-                    const int oi = redi[w * R + r];
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                besti[r] = bi;
-            }
+            for (int r = 0; r < R; ++r) besti[r] = pbesti[r];
         }
-        __syncthreads();                          // all reads of redv/redi/tok_s/fin_s done
         if (tid == 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -372,6 +401,198 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Beam search: one workgroup per image, K beams = K rows of the step (seq2seq.py:234-298 at B=1).
+// ---------------------------------------------------------------------------------------------
+struct BeamParams {
+    StepWeights w;
+    int images, T, start_id, end_id;
+    int32_t* tokhist;    // [images][T][K]  token chosen for slot q at step t
+    int32_t* parhist;    // [images][T][K]  slot (of step t-1) it extends
+    int32_t* seq_out;    // [images][T+1]
+    int32_t* len_out;    // [images]
+    double* score_out;   // [images] or null
+};
+
+template <int K>
+__global__ __launch_bounds__(NT) void beam_kernel(BeamParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const StepWeights& w = p.w;
+    const int H = w.H, L = w.L, T = p.T, V = w.V, Vp = w.Vp;
+    const int LKH = L * K * H;
+    float* hs = smem;                                   // [2][L][K][H]
+    float* cs = hs + 2 * LKH;                           // [2][L][K][H]
+    float* lg = cs + 2 * LKH;                           // [K][Vp]
+    double* score = reinterpret_cast<double*>(lg + (size_t)K * Vp);   // [K]   (offset is a multiple of 8 bytes)
+    double* nscore = score + K;                         // [K]
+    float* topv = reinterpret_cast<float*>(nscore + K); // [K][K] log-probs, descending
+    int* topi = reinterpret_cast<int*>(topv + K * K);   // [K][K]
+    int* last = topi + K * K;                           // [K] last token of each beam
+    int* live = last + K;                               // [K]
+    int* npar = live + K;                               // [K] parent slot of the new beams
+    int* ntok = npar + K;                               // [K]
+    int* ctl = ntok + K;                                // [0]=nb [1]=nlive [2]=done
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x;
+    int32_t* tokhist = p.tokhist + (size_t)img * T * K;
+    int32_t* parhist = p.parhist + (size_t)img * T * K;
+
+    for (int idx = tid; idx < 2 * LKH; idx += NT) { hs[idx] = 0.f; cs[idx] = 0.f; }
+    if (tid == 0) {
+        for (int q = 0; q < K; ++q) { score[q] = 0.0; last[q] = p.start_id; live[q] = 0; }
+        ctl[0] = 1; ctl[1] = 0; ctl[2] = 0;
+    }
+    // best completed beam so far (only thread 0 uses these)
+    bool has_c = false;
+    double best_c = 0.0;
+    int best_t = -1, best_q = 0;
+    int t_last = -1;                                    // last history row written
+    __syncthreads();
+
+    int par = 0, cpar = 0;
+    for (int t = 0; t < T; ++t) {
+        // (a) beams whose last token is END retire into `completed` (seq2seq.py:258-260), in beam order
+        if (tid == 0) {
+            const int nb = ctl[0];
+            int nl = 0;
+            for (int q = 0; q < K; ++q) {
+                int lv = 0;
+                if (q < nb) {
+                    if (last[q] == p.end_id) {
+                        if (!has_c || score[q] > best_c) { has_c = true; best_c = score[q]; best_t = t - 1; best_q = q; }
+                    } else { lv = 1; ++nl; }
+                }
+                live[q] = lv;
+            }
+            ctl[1] = nl;
+        }
+        __syncthreads();
+        if (ctl[1] == 0) break;                          // `if not candidates: break` (:276-277)
+
+        // (b) one decoder step for the K slots (retired / unused slots compute on a clamped token, ignored)
+        int tok[K], grow[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) { tok[r] = min(max(last[r], 0), V - 1); grow[r] = img; }
+        lstm_layers<K>(w, tok, grow, hs, cs + (size_t)cpar * LKH, cs + (size_t)(cpar ^ 1) * LKH, par, tid);
+        const float* h_top = hs + ((size_t)(par ^ 1) * L + (L - 1)) * K * H;
+        float* lp[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) lp[r] = nullptr;
+        float best[K];
+        int besti[K];
+        project<K>(w, h_top, lp, lg, false, 1.f, best, besti, tid);
+        __syncthreads();
+
+        // (c) log_softmax (fp32, :266) and top-K (:267: descending, lower index first on ties); wave per row
+        for (int r = wave; r < K; r += NT / 64) {
+            if (!live[r]) continue;                      // wave-uniform
+            const float* x = lg + (size_t)r * Vp;
+            float m = -INFINITY;
+            for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int v = lane; v < V; v += 64) s += expf(x[v] - m);
+            s = wave_sum(s);
+            const float lse = logf(s);
+            unsigned taken = 0;                          // bit i: element lane + 64*i already selected
+            for (int j = 0; j < K; ++j) {
+                float bv = -INFINITY;
+                int bi = 0x7fffffff;
+                for (int v = lane, i = 0; v < V; v += 64, ++i)
+                    if (!((taken >> i) & 1u) && x[v] > bv) { bv = x[v]; bi = v; }
+                wave_argmax(bv, bi);
+                if (bi < V && (bi & 63) == lane) taken |= 1u << (bi >> 6);
+                if (lane == 0) { topv[r * K + j] = (bv - m) - lse; topi[r * K + j] = bi < V ? bi : 0; }
+            }
+        }
+        __syncthreads();
+
+        // (d) candidates in (beam, rank) order, fp64 scores, stable descending selection of K (:273-280)
+        if (tid == 0) {
+            const int nlive = ctl[1];
+            const int ncand = nlive * K;
+            const int nnew = ncand < K ? ncand : K;
+            unsigned long long used = 0ull;              // K*K <= 64 candidate flags
+            for (int q = 0; q < nnew; ++q) {
+                double bs = 0.0;
+                int bc = -1;
+                for (int s0 = 0; s0 < K; ++s0) {
+                    if (!live[s0]) continue;
+                    for (int j = 0; j < K; ++j) {
+                        const int c = s0 * K + j;
+                        if ((used >> c) & 1ull) continue;
+                        const double sc = score[s0] + (double)topv[c];
+                        if (bc < 0 || sc > bs) { bs = sc; bc = c; }
+                    }
+                }
+                used |= 1ull << bc;
+                npar[q] = bc / K;
+                ntok[q] = topi[bc];
+                nscore[q] = bs;
+                tokhist[(size_t)t * K + q] = topi[bc];
+                parhist[(size_t)t * K + q] = bc / K;
+            }
+            for (int q = nnew; q < K; ++q) { npar[q] = 0; ntok[q] = 0; nscore[q] = 0.0; }
+            ctl[0] = nnew;
+            t_last = t;
+        }
+        __syncthreads();
+
+        // (e) new beam q inherits the fresh state of its parent (hidden.clone(), :272): gather into the other buffers
+        {
+            const float* hsrc = hs + (size_t)(par ^ 1) * LKH;
+            float* hdst = hs + (size_t)par * LKH;
+            const float* csrc = cs + (size_t)(cpar ^ 1) * LKH;
+            float* cdst = cs + (size_t)cpar * LKH;
+            for (int idx = tid; idx < LKH; idx += NT) {
+                const int l = idx / (K * H);
+                const int rem = idx - l * (K * H);
+                const int q = rem / H, j = rem - q * H;
+                const size_t src = ((size_t)l * K + npar[q]) * H + j;
+                hdst[idx] = hsrc[src];
+                cdst[idx] = csrc[src];
+            }
+        }
+        __syncthreads();
+        // par / cpar unchanged: the gathered state sits in hs[par], cs[cpar] again
+        if (tid == 0) {
+            const int nb = ctl[0];
+            bool all_end = true;
+            for (int q = 0; q < K; ++q) {
+                score[q] = nscore[q];
+                last[q] = ntok[q];
+                if (q < nb && ntok[q] != p.end_id) all_end = false;
+            }
+            if (all_end) {                               // completed.extend(beams); break   (:282-284)
+                for (int q = 0; q < nb; ++q)
+                    if (!has_c || score[q] > best_c) { has_c = true; best_c = score[q]; best_t = t; best_q = q; }
+                ctl[2] = 1;
+            }
+        }
+        __syncthreads();
+        if (ctl[2]) break;
+    }
+
+    // result: max(completed) (first on ties) else beams[0]; strip START, cut at END (:286-297)
+    if (tid == 0) {
+        int tt = has_c ? best_t : t_last, q = has_c ? best_q : 0;
+        const double sc = has_c ? best_c : score[0];
+        int32_t* out = p.seq_out + (size_t)img * (T + 1);
+        int n = tt + 1;                                  // tokens after START
+        for (int pos = tt; pos >= 0; --pos) {
+            out[pos] = tokhist[(size_t)pos * K + q];
+            q = parhist[(size_t)pos * K + q];
+        }
+        int len = n;
+        for (int i = 0; i < n; ++i)
+            if (out[i] == p.end_id) { len = i; break; }
+        for (int i = len; i < T + 1; ++i) out[i] = -1;
+        p.len_out[img] = len;
+        if (p.score_out) p.score_out[img] = sc;
+    }
+}
+
 int check_weights(const i2l_decoder_weights* w) {
     if (!w || !w->embedding || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->w_out || !w->b_out)
         return I2L_ERR_ARG;
@@ -380,6 +601,20 @@ int check_weights(const i2l_decoder_weights* w) {
     for (int l = 0; l < w->layers; ++l)
         if (!w->w_ih[l] || !w->w_hh[l] || !w->b_ih[l] || !w->b_hh[l]) return I2L_ERR_ARG;
     return I2L_OK;
+}
+
+StepWeights step_weights(const Layout& lo, const char* base, int V, int H, int L) {
+    auto F = [&](size_t off) { return reinterpret_cast<const float*>(base + off); };
+    StepWeights w{};
+    w.H = H; w.L = L; w.V = V; w.Vp = lo.Vp;
+    w.P = F(lo.P); w.Genc = F(lo.Genc);
+    for (int l = 0; l < L; ++l) {
+        w.WhhT[l] = F(lo.WhhT[l]);
+        w.WihT[l] = l > 0 ? F(lo.WihT[l]) : nullptr;
+        w.biasP[l] = l > 0 ? F(lo.biasP[l]) : nullptr;
+    }
+    w.WoutT = F(lo.WoutT); w.boutP = F(lo.boutP);
+    return w;
 }
 
 size_t decode_lds_bytes(int R, int L, int H, int Vp, int select) {
@@ -464,17 +699,10 @@ extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* works
     const int V = w->vocab, E = w->embed, H = w->hidden, L = w->layers;
     const Layout lo = make_layout(rows, V, E, H, L);
     const char* base = static_cast<const char*>(workspace);
-    auto F = [&](size_t off) { return reinterpret_cast<const float*>(base + off); };
 
     DecodeParams p{};
-    p.B = rows; p.H = H; p.L = L; p.V = V; p.Vp = lo.Vp; p.T = steps;
-    p.P = F(lo.P); p.Genc = F(lo.Genc);
-    for (int l = 0; l < L; ++l) {
-        p.WhhT[l] = F(lo.WhhT[l]);
-        p.WihT[l] = l > 0 ? F(lo.WihT[l]) : nullptr;
-        p.biasP[l] = l > 0 ? F(lo.biasP[l]) : nullptr;
-    }
-    p.WoutT = F(lo.WoutT); p.boutP = F(lo.boutP);
+    p.w = step_weights(lo, base, V, H, L);
+    p.B = rows; p.T = steps;
     p.tok0 = tok0; p.forced = forced; p.h0 = h0; p.c0 = c0;
     p.h_out = h_out; p.c_out = c_out; p.ids = ids_out; p.logits = logits_out;
     p.temperature = temperature; p.use_temp = (temperature != 1.0f) ? 1 : 0;
@@ -492,4 +720,68 @@ extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* works
     else hipLaunchKernelGGL(decode_kernel<4>, grid, dim3(NT), lds, s, p);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
+}
+
+namespace {
+
+size_t beam_lds_bytes(int K, int L, int H, int Vp) {
+    size_t b = (size_t)4 * L * K * H * sizeof(float) + (size_t)K * Vp * sizeof(float);
+    b = (b + 7) / 8 * 8;
+    b += 2 * (size_t)K * sizeof(double) + (size_t)2 * K * K * 4 + (size_t)4 * K * 4 + 4 * 4;
+    return b;
+}
+
+template <int K>
+int launch_beam(const BeamParams& p, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_kernel<K>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return I2L_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(beam_kernel<K>, dim3(p.images), dim3(NT), lds, s, p);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+}  // namespace
+
+extern "C" size_t i2l_beam_workspace_bytes(int images, int beam, int hidden, int layers, int steps) {
+    (void)hidden; (void)layers;
+    if (images <= 0 || beam <= 0 || beam > I2L_MAX_BEAM || steps <= 0) return 0;
+    return i2l_align((size_t)2 * images * steps * beam * sizeof(int32_t));
+}
+
+extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspace, int images, int beam, int steps,
+                               int start_id, int end_id, void* beam_workspace, size_t beam_workspace_bytes,
+                               int32_t* seq_out, int32_t* len_out, double* score_out, i2l_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc != I2L_OK) return rc;
+    if (!workspace || !beam_workspace || !seq_out || !len_out || images <= 0 || steps <= 0 || beam <= 0)
+        return I2L_ERR_ARG;
+    if (beam > I2L_MAX_BEAM || beam > w->vocab) return I2L_ERR_UNSUPPORTED;
+    const size_t need = (size_t)2 * images * steps * beam * sizeof(int32_t);
+    if (beam_workspace_bytes < need) return I2L_ERR_WORKSPACE;
+    const int V = w->vocab, E = w->embed, H = w->hidden, L = w->layers;
+    const Layout lo = make_layout(images, V, E, H, L);
+    if (lo.Vp > 64 * 32) return I2L_ERR_UNSUPPORTED;      // top-k exclusion mask: 32 elements per lane
+    BeamParams p{};
+    p.w = step_weights(lo, static_cast<const char*>(workspace), V, H, L);
+    p.images = images; p.T = steps; p.start_id = start_id; p.end_id = end_id;
+    p.tokhist = static_cast<int32_t*>(beam_workspace);
+    p.parhist = p.tokhist + (size_t)images * steps * beam;
+    p.seq_out = seq_out; p.len_out = len_out; p.score_out = score_out;
+    const size_t lds = beam_lds_bytes(beam, L, H, lo.Vp);
+    if (lds > 160 * 1024) return I2L_ERR_UNSUPPORTED;
+    hipStream_t s = i2l_s(stream);
+    switch (beam) {
+        case 1: return launch_beam<1>(p, lds, s);
+        case 2: return launch_beam<2>(p, lds, s);
+        case 3: return launch_beam<3>(p, lds, s);
+        case 4: return launch_beam<4>(p, lds, s);
+        case 5: return launch_beam<5>(p, lds, s);
+        case 6: return launch_beam<6>(p, lds, s);
+        case 7: return launch_beam<7>(p, lds, s);
+        case 8: return launch_beam<8>(p, lds, s);
+        default: return I2L_ERR_UNSUPPORTED;
+    }
 }

@@ -216,3 +216,59 @@ def test_rows_are_independent_and_batch_tail():
         idsb, _ = m.greedy_ids(big, START, END, 20)
     assert torch.equal(ids7[3], ids1[0])
     assert torch.equal(idsb[: 7], ids7) and torch.equal(idsb[623:630], ids7)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_beam_search_vs_golden(name):
+    """seq2seq.py:234-298: N independent batch-1 beam searches in one launch."""
+    d, cfg, _ = load(name)
+    m, _ = model_for(name)
+    bimgs = images(cfg, 8, seed=4321, device=DEV)
+    with torch.no_grad():
+        enc = m.encoder(bimgs)
+        for k in (5, 3):
+            want = padded_to_lists(d[f"g4_k{k}_ids"], d[f"g4_k{k}_len"])
+            got, scores = m.beam_search_batch(enc, START, END, 40, k, return_scores=True)
+            assert got == want, (name, k)
+            assert all(np.isfinite(s) and s <= 0.0 for s in scores)
+        one = m.inference(bimgs[2:3], START, END, max_length=40, beam_size=5)   # the reference's entry point
+    assert one == padded_to_lists(d["g4_k5_ids"], d["g4_k5_len"])[2]
+
+
+def test_beam_scores_vs_oracle():
+    d, cfg, _ = load("tiny_l2_attn")
+    m, _ = model_for("tiny_l2_attn")
+    sd = torch_state_dict("tiny_l2_attn")
+    bimgs = images(cfg, 6, seed=77)
+    with torch.no_grad():
+        enc_cpu = O.cnn_encoder(sd, cfg, bimgs)
+        got, scores = m.beam_search_batch(m.encoder(bimgs.to(DEV)), START, END, 30, 4, return_scores=True)
+        for j in range(6):
+            seq, sc = O.beam_search(sd, cfg, enc_cpu[j:j + 1], START, END, 30, 4, return_score=True)
+            assert got[j] == seq
+            assert abs(scores[j] - sc) <= 1e-4 * max(1.0, abs(sc))
+        # k = 1 beam == greedy until END; max beam width; START == END degenerate case
+        g1, _ = m.beam_search_batch(m.encoder(bimgs.to(DEV)), START, END, 30, 1, return_scores=True)
+        for j in range(6):
+            assert g1[j] == O.beam_search(sd, cfg, enc_cpu[j:j + 1], START, END, 30, 1)
+        g8 = m.beam_search_batch(m.encoder(bimgs.to(DEV)), START, END, 12, 8)
+        for j in range(2):
+            assert g8[j] == O.beam_search(sd, cfg, enc_cpu[j:j + 1], START, END, 12, 8)
+        assert m.beam_search_batch(m.encoder(bimgs.to(DEV)), START, START, 5, 3)[0] == []
+
+
+def test_attention_general_length():
+    from img2latex_amd.model import Attention
+    torch.manual_seed(3)
+    for (B, S, H, E) in [(3, 1, 64, 32), (4, 7, 64, 32), (2, 33, 128, 96)]:
+        att = Attention(H, E)
+        sd = {"decoder.attention.attn.weight": att.attn.weight.detach().clone(),
+              "decoder.attention.attn.bias": att.attn.bias.detach().clone(),
+              "decoder.attention.v.weight": att.v.weight.detach().clone()}
+        hid, enc = torch.randn(B, 1, H), torch.randn(B, S, E)
+        with torch.no_grad():
+            want = O.attention_context(sd, hid, enc)
+            got = att.to(DEV)(hid.to(DEV), enc.to(DEV)).cpu()
+        close(got.numpy(), want.numpy(), 1e-5)
+        if S == 1:                                   # identity, bit for bit (fixture G7)
+            assert torch.equal(got, enc)
