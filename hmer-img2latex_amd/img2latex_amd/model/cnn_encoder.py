@@ -74,8 +74,11 @@ class CNNEncoder(nn.Module):
             y = torch.empty((B, conv.out_channels, h // 2, w // 2), dtype=torch.float32, device=x.device)
             wt = _lib.require_gpu(conv.weight.detach(), "conv weight")
             bs = _lib.require_gpu(conv.bias.detach(), "conv bias")
+            nbytes = L.i2l_conv_workspace_bytes(cin, conv.out_channels)
+            ws = self._workspace(nbytes, x.device)
             _lib.check(L.i2l_conv3x3_relu_pool2_fwd(x.data_ptr(), wt.data_ptr(), bs.data_ptr(), y.data_ptr(),
-                                                    B, cin, h, w, conv.out_channels, _lib.stream_ptr()),
+                                                    B, cin, h, w, conv.out_channels, _lib.ptr(ws), nbytes,
+                                                    _lib.stream_ptr()),
                        "conv3x3_relu_pool2_fwd")
             _lib.mark(f"conv{i}")
             outs.append(y)

@@ -49,8 +49,10 @@ const char* i2l_error_string(int code);
 /* One CNN block: y = maxpool2x2(relu(conv3x3_pad1(x, w) + bias)), floor pooling.
  * Replaces nn.Conv2d + nn.ReLU + nn.MaxPool2d, encoder.py:78-95 executed at :122.
  * x (B,Cin,H,W)  w (Cout,Cin,3,3)  bias (Cout)  y (B,Cout,H/2,W/2), NCHW fp32. */
+size_t i2l_conv_workspace_bytes(int Cin, int Cout);   /* packed-weight scratch; 0 when none is needed */
 int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias, float* y,
-                               int B, int Cin, int H, int W, int Cout, i2l_stream_t stream);
+                               int B, int Cin, int H, int W, int Cout, void* workspace,
+                               size_t workspace_bytes, i2l_stream_t stream);
 
 /* y = act(x @ w^T + bias): nn.Flatten + nn.Linear + nn.ReLU, encoder.py:105-107,125-127
  * (also nn.Linear(Hd->V), decoder.py:90).  x (M,K)  w (N,K)  bias (N) or NULL  y (M,N).

@@ -185,20 +185,24 @@ def test_linear_kernel_odd_shapes():
 def test_conv_kernel_odd_shapes():
     torch.manual_seed(1)
     L = _lib.lib()
-    for (B, Cin, H, W, Cout) in [(1, 1, 2, 2, 1), (2, 3, 7, 9, 5), (3, 5, 16, 70, 9), (2, 16, 33, 131, 24), (1, 64, 16, 80, 128)]:
+    for (B, Cin, H, W, Cout) in [(1, 1, 2, 2, 1), (2, 3, 7, 9, 5), (3, 5, 16, 70, 9), (2, 16, 33, 131, 24),
+                                 (1, 64, 16, 80, 128), (2, 3, 64, 320, 32), (2, 5, 23, 71, 96), (3, 9, 7, 9, 32),
+                                 (1, 32, 32, 160, 64), (2, 1, 2, 2, 64)]:
         x, w, b = torch.randn(B, Cin, H, W), torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5), torch.randn(Cout)
         want = O.conv_block(x, w, b)
         y = torch.empty(B, Cout, H // 2, W // 2, device=DEV)
         xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)             # keep the device copies alive
+        nbytes = L.i2l_conv_workspace_bytes(Cin, Cout)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
         rc = L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(),
-                                          y.data_ptr(), B, Cin, H, W, Cout, _lib.stream_ptr())
+                                          y.data_ptr(), B, Cin, H, W, Cout, ws.data_ptr(), nbytes, _lib.stream_ptr())
         assert rc == 0
         close(y.cpu().numpy(), want.numpy(), 1e-5)
 
 
 def test_error_codes_not_exceptions():
     L = _lib.lib()
-    assert L.i2l_conv3x3_relu_pool2_fwd(None, None, None, None, 1, 1, 4, 4, 1, None) == -1
+    assert L.i2l_conv3x3_relu_pool2_fwd(None, None, None, None, 1, 1, 4, 4, 1, None, 0, None) == -1
     assert L.i2l_linear_bias_act_fwd(None, None, None, None, 1, 1, 1, 0, None, 0, None) == -1
 
 
