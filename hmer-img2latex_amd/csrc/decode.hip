@@ -113,48 +113,69 @@ struct DecodeParams {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // acc[r] += sum_k W[k][0..3] * x[r][k], k ascending (one fmaf chain per output).
+// The weight stream is software-pipelined: while the FMAs of one batch of PF rows run, the
+// loads of the next batch are already in flight (two register sets, counted vmcnt by the
+// compiler), so one wave per SIMD keeps ~PF 16-byte loads per lane outstanding.
+constexpr int PF = 16;
+
+template <int R, int NV>   // NV = 4 (float4: LSTM gates) or 2 (float2: vocabulary projection)
+struct WVec;
 template <int R>
-__device__ __forceinline__ void matvec4(float4 (&acc)[R], const float* __restrict__ Wcol, size_t ldw,
-                                        const float* xs, int H) {
-    for (int k = 0; k < H; k += 8) {
-        float4 w[8];
+struct WVec<R, 4> { typedef float4 type; };
+template <int R>
+struct WVec<R, 2> { typedef float2 type; };
+
+template <int R>
+__device__ __forceinline__ void fma_rows(float4 (&acc)[R], const float4 (&w)[PF], const float* xs, int H, int k) {   // H = row stride of xs
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float4*>(Wcol + (size_t)(k + i) * ldw);
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float4 xa = *reinterpret_cast<const float4*>(xs + r * H + k);
-            const float4 xb = *reinterpret_cast<const float4*>(xs + r * H + k + 4);
-            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        for (int i4 = 0; i4 < PF; i4 += 4) {
+            const float4 xa = *reinterpret_cast<const float4*>(xs + r * H + k + i4);
+            const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[r].x = fmaf(w[i].x, xv[i], acc[r].x);
-                acc[r].y = fmaf(w[i].y, xv[i], acc[r].y);
-                acc[r].z = fmaf(w[i].z, xv[i], acc[r].z);
-                acc[r].w = fmaf(w[i].w, xv[i], acc[r].w);
+            for (int i = 0; i < 4; ++i) {
+                acc[r].x = fmaf(w[i4 + i].x, xv[i], acc[r].x);
+                acc[r].y = fmaf(w[i4 + i].y, xv[i], acc[r].y);
+                acc[r].z = fmaf(w[i4 + i].z, xv[i], acc[r].z);
+                acc[r].w = fmaf(w[i4 + i].w, xv[i], acc[r].w);
             }
         }
     }
 }
 
-template <int R>
-__device__ __forceinline__ void matvec2(float2 (&acc)[R], const float* __restrict__ Wcol, size_t ldw,
-                                        const float* xs, int H) {
-    for (int k = 0; k < H; k += 8) {
-        float2 w[8];
+template <int R, typename VT>
+__device__ __forceinline__ void matvec(VT (&acc)[R], const float* __restrict__ Wcol, size_t ldw, const float* xs,
+                                       int xstride, int H) {   // H = number of k (multiple of 32), xstride = row stride of xs
+    VT wa[PF], wb[PF];
+    // No load sits under a condition: the compiler can then count outstanding loads exactly
+    // (s_waitcnt vmcnt(PF) before a batch is used) instead of draining to vmcnt(0) at a join.
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float2*>(Wcol + (size_t)(k + i) * ldw);
+    for (int i = 0; i < PF; ++i) wa[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)i * ldw);
+    int k = 0;
+    for (; k + 2 * PF < H; k += 2 * PF) {                 // H % 32 == 0
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float4 xa = *reinterpret_cast<const float4*>(xs + r * H + k);
-            const float4 xb = *reinterpret_cast<const float4*>(xs + r * H + k + 4);
-            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        for (int i = 0; i < PF; ++i) wb[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)(k + PF + i) * ldw);
+        __builtin_amdgcn_sched_barrier(0);                // keep the batch of loads ahead of the FMAs
+        fma_rows<R>(acc, wa, xs, xstride, k);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[r].x = fmaf(w[i].x, xv[i], acc[r].x);
-                acc[r].y = fmaf(w[i].y, xv[i], acc[r].y);
-            }
-        }
+        for (int i = 0; i < PF; ++i) wa[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)(k + 2 * PF + i) * ldw);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_rows<R>(acc, wb, xs, xstride, k + PF);
+        __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) wb[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)(k + PF + i) * ldw);
+    __builtin_amdgcn_sched_barrier(0);
+    fma_rows<R>(acc, wa, xs, xstride, k);
+    fma_rows<R>(acc, wb, xs, xstride, k + PF);
+}
+
+template <int R>
+__device__ __forceinline__ void matvec4(float4 (&acc)[R], const float* __restrict__ Wcol, size_t ldw,
+                                        const float* xs, int H) {
+    matvec<R, float4>(acc, Wcol, ldw, xs, H, H);
 }
 
 // (value, index) max with "first index wins" over the 64 lanes of a wave.
@@ -221,33 +242,47 @@ __device__ __forceinline__ void lstm_layers(const StepWeights& w, const int (&to
     }
 }
 
-// logits = h_top @ W_out^T + b for R rows; thread t owns columns 2t, 2t+1 (+512 per pass).
-// Optionally writes raw logits to global (lp[r] != null), keeps (logit / temperature) in LDS (lg != null),
-// and returns each thread's running (max, first index) over its columns.
+// logits = h_top @ W_out^T + b for R rows, 512 vocabulary columns per pass.  16-byte loads only
+// (8-byte streams run at ~0.55x the 16-byte rate on gfx950): thread t owns the 4 columns
+// 4*(t&127).. and HALF of k -- threads 0-127 sum k < H/2 (starting from the bias), threads 128-255
+// sum k >= H/2; the two partial chains meet through LDS (psum) in a fixed order, so results are
+// deterministic.  Optionally writes raw logits to global (lp[r] != null), keeps logit/temperature
+// in LDS (lg != null), and returns each thread's running (max, first index); upper-half threads
+// return -inf.  Contains __syncthreads(); every thread of the workgroup must call it.
 template <int R>
 __device__ __forceinline__ void project(const StepWeights& w, const float* h_top, float* const (&lp)[R],
                                         float* lg, bool use_temp, float temperature, float (&best)[R],
-                                        int (&besti)[R], int tid) {
+                                        int (&besti)[R], float* psum, int tid) {
+    const int half = tid >> 7, c4 = (tid & 127) * 4;
+    const int Hh = w.H >> 1;
 #pragma unroll
     for (int r = 0; r < R; ++r) { best[r] = -INFINITY; besti[r] = 0x7fffffff; }
-    for (int v0 = 2 * tid; v0 < w.Vp; v0 += VCHUNK) {
-        float2 acc[R];
-        const float2 bb = *reinterpret_cast<const float2*>(w.boutP + v0);
+    for (int v0 = c4; v0 < w.Vp; v0 += VCHUNK) {
+        float4 acc[R];
+        const float4 bb = half == 0 ? *reinterpret_cast<const float4*>(w.boutP + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = bb;
-        matvec2<R>(acc, w.WoutT + v0, (size_t)w.Vp, h_top, w.H);
+        matvec<R, float4>(acc, w.WoutT + (size_t)half * Hh * w.Vp + v0, (size_t)w.Vp, h_top + half * Hh, w.H, Hh);
+        if (half == 1) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (lp[r]) {
-                if (v0 < w.V) lp[r][v0] = acc[r].x;
-                if (v0 + 1 < w.V) lp[r][v0 + 1] = acc[r].y;
-            }
-            float a = acc[r].x, b2 = acc[r].y;
-            if (use_temp) { a = a / temperature; b2 = b2 / temperature; }
-            if (lg) { lg[r * w.Vp + v0] = a; lg[r * w.Vp + v0 + 1] = b2; }
-            if (a > best[r]) { best[r] = a; besti[r] = v0; }
-            if (b2 > best[r]) { best[r] = b2; besti[r] = v0 + 1; }
+            for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(psum + ((size_t)r * 128 + (tid & 127)) * 4) = acc[r];
         }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 u = *reinterpret_cast<const float4*>(psum + ((size_t)r * 128 + tid) * 4);
+                float a[4] = {acc[r].x + u.x, acc[r].y + u.y, acc[r].z + u.z, acc[r].w + u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (lp[r] && v0 + e < w.V) lp[r][v0 + e] = a[e];
+                    if (use_temp) a[e] = a[e] / temperature;
+                    if (lg) lg[r * w.Vp + v0 + e] = a[e];
+                    if (a[e] > best[r]) { best[r] = a[e]; besti[r] = v0 + e; }
+                }
+            }
+        }
+        if (v0 + VCHUNK < w.Vp) __syncthreads();          // psum is reused by the next pass
     }
 }
 
@@ -288,7 +323,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
     int* redi = reinterpret_cast<int*>(redv + 4 * R);   // [4][R]
     int* tok_s = redi + 4 * R;                 // [R]
     int* fin_s = tok_s + R;                    // [R]
-    float* lg = reinterpret_cast<float*>(fin_s + R);    // [R][Vp], only with I2L_SELECT_SOFTMAX
+    float* psum = reinterpret_cast<float*>(fin_s + R + ((4 - ((10 * R) & 3)) & 3));   // [R][128][4], 16-byte aligned
+    float* lg = psum + R * 512;                         // [R][Vp], only with I2L_SELECT_SOFTMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * R;
@@ -330,7 +366,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
         float best[R];
         int besti[R];
         project<R>(w, h_top, lp, p.select == I2L_SELECT_SOFTMAX ? lg : nullptr, p.use_temp != 0, p.temperature,
-                   best, besti, tid);
+                   best, besti, psum, tid);
         block_argmax<R>(best, besti, redv, redi, tid);
         if (p.select == I2L_SELECT_SOFTMAX) {
             // argmax(softmax(x)): probabilities in fp32 as torch.softmax (exp(x - max) / sum), first index wins
@@ -423,7 +459,8 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamParams p) {
     float* hs = smem;                                   // [2][L][K][H]
     float* cs = hs + 2 * LKH;                           // [2][L][K][H]
     float* lg = cs + 2 * LKH;                           // [K][Vp]
-    double* score = reinterpret_cast<double*>(lg + (size_t)K * Vp);   // [K]   (offset is a multiple of 8 bytes)
+    float* psum = lg + (size_t)K * Vp;                  // [K][128][4]
+    double* score = reinterpret_cast<double*>(psum + K * 512);   // [K]   (offset is a multiple of 8 bytes)
     double* nscore = score + K;                         // [K]
     float* topv = reinterpret_cast<float*>(nscore + K); // [K][K] log-probs, descending
     int* topi = reinterpret_cast<int*>(topv + K * K);   // [K][K]
@@ -481,7 +518,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamParams p) {
         for (int r = 0; r < K; ++r) lp[r] = nullptr;
         float best[K];
         int besti[K];
-        project<K>(w, h_top, lp, lg, false, 1.f, best, besti, tid);
+        project<K>(w, h_top, lp, lg, false, 1.f, best, besti, psum, tid);
         __syncthreads();
 
         // (c) log_softmax (fp32, :266) and top-K (:267: descending, lower index first on ties); wave per row
@@ -618,7 +655,7 @@ StepWeights step_weights(const Layout& lo, const char* base, int V, int H, int L
 }
 
 size_t decode_lds_bytes(int R, int L, int H, int Vp, int select) {
-    size_t floats = (size_t)3 * L * R * H + 4 * R + 4 * R + R + R;
+    size_t floats = (size_t)3 * L * R * H + 4 * R + 4 * R + R + R + 4 + (size_t)R * 512;
     if (select == I2L_SELECT_SOFTMAX) floats += (size_t)R * Vp;
     return floats * sizeof(float);
 }
@@ -725,7 +762,7 @@ extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* works
 namespace {
 
 size_t beam_lds_bytes(int K, int L, int H, int Vp) {
-    size_t b = (size_t)4 * L * K * H * sizeof(float) + (size_t)K * Vp * sizeof(float);
+    size_t b = (size_t)4 * L * K * H * sizeof(float) + (size_t)K * Vp * sizeof(float) + (size_t)K * 512 * sizeof(float);
     b = (b + 7) / 8 * 8;
     b += 2 * (size_t)K * sizeof(double) + (size_t)2 * K * K * 4 + (size_t)4 * K * 4 + 4 * 4;
     return b;
