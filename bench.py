@@ -30,6 +30,7 @@ import torch  # noqa: E402
 
 from img2latex_amd import _lib, synth  # noqa: E402
 from img2latex_amd.model import Seq2SeqModel  # noqa: E402
+from img2latex_amd.pipeline import GreedyPipeline  # noqa: E402
 
 # MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_HBM_GBS = 8000.0
@@ -63,6 +64,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--seq", type=int, default=150, help="decode steps (max_length)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="two streams: encoder of batch i+1 overlaps decode of batch i (default: one stream, "
+                         "batches back to back, so the per-kernel event times are undisturbed)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,13 +98,24 @@ def main():
         ev.record(torch.cuda.current_stream())
         events.append((name, ev))
 
+    pipe = GreedyPipeline(model, synth.START, synth.END, T, depth=2) if args.overlap else None
+    last = [ids_host]
+
     def one_step():
-        with torch.no_grad():
-            enc = model.encoder(images)
-            ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
-            ids_host.copy_(ids, non_blocking=True)
+        if pipe is None:
+            with torch.no_grad():
+                enc = model.encoder(images)
+                ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
+                ids_host.copy_(ids, non_blocking=True)
+        else:
+            if pipe.pending() >= 2:
+                last[0] = pipe.collect()
+            pipe.submit(images)
 
     def fence():
+        if pipe is not None:
+            while pipe.pending():
+                last[0] = pipe.collect()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -118,6 +133,7 @@ def main():
     _lib.set_stage_hook(None)
 
     # steps actually executed by the reference's stop rule (all rows END in one step, seq2seq.py:220)
+    ids_host = last[0]
     all_end = (ids_host == synth.END).all(dim=0)
     executed = int(all_end.nonzero()[0]) + 1 if bool(all_end.any()) else T
     tokens_per_step = B * executed
@@ -177,7 +193,8 @@ def main():
                    "global_batch": B * world, "image": "3x64x320", "decode_steps": executed,
                    "embedding_dim": cfg["embedding_dim"], "hidden_dim": cfg["hidden_dim"],
                    "lstm_layers": cfg["lstm_layers"], "vocab": cfg["vocab_size"],
-                   "parallelism": f"replicas x{world} (no collective)"},
+                   "parallelism": f"replicas x{world} (no collective)",
+                   "batch_pipeline": "2 streams: encoder(i+1) overlaps decode(i)" if args.overlap else "serial"},
         "roofline": roofline,
     }
 

@@ -1,0 +1,94 @@
+"""Two-stage batch pipeline for greedy inference on one GPU.
+
+Images are independent, so consecutive batches can overlap: the encoder of batch i+1
+(fp32-MFMA bound, thousands of short workgroups) runs on one HIP stream while the
+persistent decode loop of batch i (one workgroup per CU, bound by the L2->CU weight
+stream, mostly waiting) runs on another.  Their workgroups fit on a CU side by side
+(decode: 4 waves x 240 VGPRs; conv: 128 VGPRs, 34 KB LDS), so the hardware interleaves
+them and steady-state time per batch approaches max(encoder, decode) instead of the sum.
+
+Nothing is skipped: every batch still runs the full encoder, decoder prepare, decode loop
+and id copy; results equal ``Seq2SeqModel._greedy_search`` batch by batch.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Deque, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+class GreedyPipeline:
+    """submit(images) enqueues one batch; results come back in order from collect()."""
+
+    def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
+                 temperature: float = 1.0, depth: int = 2):
+        self.model = model
+        self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("img2latex_amd: GreedyPipeline needs the model on a ROCm device (no CPU fallback)")
+        self.device = dev
+        self.enc_stream = torch.cuda.Stream(device=dev)
+        self.dec_stream = torch.cuda.Stream(device=dev)
+        self.depth = depth
+        self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor]] = deque()
+        self._free: List[torch.Tensor] = []          # pinned host buffers not in use
+        self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
+
+    def submit(self, images: torch.Tensor) -> None:
+        """Enqueue encoder (stream A) and prepare + decode + id copy (stream B) for one batch."""
+        if len(self._inflight) >= self.depth:
+            raise RuntimeError(f"GreedyPipeline: {self.depth} batches already in flight; collect() first")
+        cur = torch.cuda.current_stream(self.device)
+        self.enc_stream.wait_stream(cur)                      # images were produced on the caller's stream
+        with torch.no_grad():
+            with torch.cuda.stream(self.enc_stream):
+                enc = self.model.encoder(images)
+                enc_done = torch.cuda.Event()
+                enc_done.record(self.enc_stream)
+            images.record_stream(self.enc_stream)
+            with torch.cuda.stream(self.dec_stream):
+                self.dec_stream.wait_event(enc_done)
+                enc.record_stream(self.dec_stream)
+                ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature)
+                host = self._host_buffer(ids.shape)
+                host.copy_(ids, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.dec_stream)
+        self._inflight.append((done, host))
+
+    def _host_buffer(self, shape) -> torch.Tensor:
+        for i, t in enumerate(self._free):
+            if t.shape == shape:
+                return self._free.pop(i)
+        return torch.empty(shape, dtype=torch.int32).pin_memory()
+
+    def pending(self) -> int:
+        return len(self._inflight)
+
+    def collect(self) -> Optional[torch.Tensor]:
+        """Oldest finished batch: (B, steps) int32 ids in pinned host memory, valid until the next
+        collect(); ``to_sequences`` applies the reference's stop rule and list conversion."""
+        if not self._inflight:
+            return None
+        done, host = self._inflight.popleft()
+        done.synchronize()
+        if self._lent is not None:
+            self._free.append(self._lent)
+        self._lent = host
+        return host
+
+    def drain(self) -> List[torch.Tensor]:
+        out = []
+        while self._inflight:
+            out.append(self.collect().clone())
+        return out
+
+    def to_sequences(self, ids_host: torch.Tensor):
+        """The reference's post-processing of ``_greedy_search`` (seq2seq.py:217-232) for B > 1."""
+        all_end = (ids_host == self.end).all(dim=0)
+        steps = int(all_end.nonzero()[0]) + 1 if bool(all_end.any()) else ids_host.shape[1]
+        return [[self.start] + r for r in ids_host[:, :steps].tolist()]

@@ -276,3 +276,26 @@ def test_attention_general_length():
         close(got.numpy(), want.numpy(), 1e-5)
         if S == 1:                                   # identity, bit for bit (fixture G7)
             assert torch.equal(got, enc)
+
+
+def test_greedy_pipeline_matches_serial():
+    """Two-stream batch pipeline returns exactly what the serial search returns, batch by batch."""
+    from img2latex_amd.pipeline import GreedyPipeline
+    d, cfg, _ = load("tiny_l1")
+    m, _ = model_for("tiny_l1")
+    batches = [images(cfg, batch=5, seed=100 + i, device=DEV) for i in range(6)]
+    with torch.no_grad():
+        want = [m.inference(b, START, END, max_length=32) for b in batches]
+    pipe = GreedyPipeline(m, START, END, 32, depth=2)
+    got = []
+    for b in batches:
+        if pipe.pending() >= 2:
+            got.append(pipe.to_sequences(pipe.collect()))
+        pipe.submit(b)
+    while pipe.pending():
+        got.append(pipe.to_sequences(pipe.collect()))
+    assert got == want
+    with pytest.raises(RuntimeError):
+        for b in batches[:3]:
+            pipe.submit(b)
+    pipe.drain()
