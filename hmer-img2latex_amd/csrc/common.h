@@ -14,17 +14,27 @@ static inline hipStream_t i2l_s(i2l_stream_t s) { return reinterpret_cast<hipStr
 static inline int i2l_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t i2l_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// ---- generic fp32 NT GEMM (gemm.hip):  C[m][n] = act(sum_k A[m][k] * W[n][k] + bias[n])
-// perm_h > 0: output column n = g*perm_h + j is stored at column 4*j + g (LSTM gate interleave).
+// ---- generic fp32 MFMA GEMM (gemm.hip):
+//   C[m][n] (+)= alpha * act(sum_z sum_k A_z(m,k) * W_z(n,k) + bias[n] + bias2[n])
+//   a_kc != 0: A(m,k) = A[m*lda + k] (K-contiguous) else A[k*lda + m];  same for W with n.
+//   perm_h > 0: output column n = g*perm_h + j is stored at column 4*j + g (LSTM gate interleave).
 struct GemmArgs {
-    const float* A; int lda;
-    const float* W; int ldw;
+    const float* A; long lda; int a_kc;
+    const float* W; long ldw; int w_kc;
+    long bsa, bsw; int nz;    // nz operand pairs (A + z*bsa, W + z*bsw) are summed
     const float* bias;        // may be null
     const float* bias2;       // may be null (added as well)
     float* C; int ldc;
     int M, N, K;
     int relu;
     int perm_h;
+    float alpha;
+    int accumulate;           // C += result instead of C = result
 };
-size_t i2l_gemm_workspace_bytes(int M, int N, int K);
-int i2l_gemm_nt(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s);
+static inline GemmArgs gemm_args() {
+    GemmArgs g{};
+    g.a_kc = 1; g.w_kc = 1; g.nz = 1; g.alpha = 1.f;
+    return g;
+}
+size_t i2l_gemm_workspace_bytes(int M, int N, int K, int nz = 1);
+int i2l_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s);

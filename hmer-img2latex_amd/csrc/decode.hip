@@ -764,22 +764,22 @@ extern "C" int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* en
     }
     const size_t gws = lo.total - lo.gemm_ws;
     if (what & I2L_PREP_WEIGHTS) {   // P = Emb @ W_ih_0[:, :E]^T, gate-interleaved columns
-        GemmArgs g{};
+        GemmArgs g = gemm_args();
         g.A = w->embedding; g.lda = E;
         g.W = w->w_ih[0]; g.ldw = 2 * E;
         g.C = F(lo.P); g.ldc = G;
         g.M = V; g.N = G; g.K = E; g.perm_h = H;
-        rc = i2l_gemm_nt(g, base + lo.gemm_ws, gws, s);
+        rc = i2l_gemm(g, base + lo.gemm_ws, gws, s);
         if (rc != I2L_OK) return rc;
     }
     if (what & I2L_PREP_ROWS) {   // Genc = enc @ W_ih_0[:, E:]^T + b_ih_0 + b_hh_0
-        GemmArgs g{};
+        GemmArgs g = gemm_args();
         g.A = enc; g.lda = E;
         g.W = w->w_ih[0] + E; g.ldw = 2 * E;
         g.bias = w->b_ih[0]; g.bias2 = w->b_hh[0];
         g.C = F(lo.Genc); g.ldc = G;
         g.M = rows; g.N = G; g.K = E; g.perm_h = H;
-        rc = i2l_gemm_nt(g, base + lo.gemm_ws, gws, s);
+        rc = i2l_gemm(g, base + lo.gemm_ws, gws, s);
         if (rc != I2L_OK) return rc;
     }
     return I2L_OK;

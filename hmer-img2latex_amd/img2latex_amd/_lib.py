@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
 from typing import Optional, Sequence
 
 import torch
@@ -29,6 +29,12 @@ class DecoderWeights(ctypes.Structure):
                 ("b_out", c_void_p), ("vocab", c_int), ("embed", c_int), ("hidden", c_int), ("layers", c_int)]
 
 
+class DecoderGrads(ctypes.Structure):
+    """struct i2l_decoder_grads."""
+    _fields_ = [("embedding", c_void_p), ("w_ih", POINTER(c_void_p)), ("w_hh", POINTER(c_void_p)),
+                ("b_ih", POINTER(c_void_p)), ("b_hh", POINTER(c_void_p)), ("w_out", c_void_p), ("b_out", c_void_p)]
+
+
 _SIGNATURES = {
     "i2l_version": (c_int, []),
     "i2l_error_string": (c_char_p, [c_int]),
@@ -48,6 +54,14 @@ _SIGNATURES = {
                                 c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "i2l_attention_context_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                           c_int, c_int, c_void_p]),
+    "i2l_decoder_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "i2l_decoder_train_fwd": (c_int, [POINTER(DecoderWeights), c_void_p, c_void_p, c_int, c_int, c_float, c_uint64,
+                                      c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "i2l_decoder_train_bwd": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_float, c_uint64, c_int,
+                                      c_void_p, c_size_t, c_void_p, POINTER(DecoderGrads), c_void_p, c_void_p]),
+    "i2l_ce_workspace_bytes": (c_size_t, [c_int]),
+    "i2l_ce_label_smooth_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t,
+                                            c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -166,15 +166,22 @@ class LSTMDecoder(nn.Module):
     # ------------------------------------------------------------------ reference surface
     def forward(self, encoder_output: torch.Tensor, target_sequence: torch.Tensor, hidden=None) -> torch.Tensor:
         """Teacher forcing (decoder.py:100-195): (B,E), (B,T) int64 -> logits (B,T,V).
-        Inference/eval semantics (dropout is identity); the training path with backward
-        is the training-step entry point."""
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("img2latex_amd: decoder backward is not built yet (use eval()/no_grad())")
+        With gradients enabled (or dropout active) the training kernels run and the result
+        carries a grad_fn; otherwise the persistent decode kernel runs with forced tokens."""
         tgt = target_sequence
         if not tgt.is_cuda:
             raise RuntimeError("img2latex_amd: target_sequence must be on the ROCm device (no CPU fallback)")
         B, T = tgt.shape
         forced = tgt.to(torch.int32).contiguous()
+        needs_grad = torch.is_grad_enabled() and (encoder_output.requires_grad
+                                                  or any(p.requires_grad for p in self.parameters()))
+        if needs_grad or (self.training and self.dropout > 0):
+            # training-mode forward: keeps the BPTT state; dropout masks are drawn from a fresh seed
+            if hidden is not None:
+                raise NotImplementedError("img2latex_amd: training forward starts from a zero state (as the Trainer does)")
+            from ._train_fn import DecoderTeacherForcedFn
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            return DecoderTeacherForcedFn.apply(self, encoder_output, forced, seed, *self.parameters())
         _, logits, _ = self.run_steps(encoder_output, T, forced[:, 0].contiguous(), forced=forced, hidden=hidden,
                                       want_ids=False, want_logits=True)
         return logits

@@ -148,6 +148,46 @@ int i2l_attention_context_fwd(const float* hidden, const float* enc, const float
                               const float* b_attn, const float* v, float* context,
                               int B, int S, int H, int E, i2l_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Training step (reference img2latex/training/trainer.py:303-343, fp32 branch)
+ * ---------------------------------------------------------------------- */
+
+/* Gradient buffers, same shapes / key names as i2l_decoder_weights (HOST arrays of device pointers). */
+typedef struct i2l_decoder_grads {
+    float* embedding;
+    float* const* w_ih;
+    float* const* w_hh;
+    float* const* b_ih;
+    float* const* b_hh;
+    float* w_out;
+    float* b_out;
+} i2l_decoder_grads;
+
+/* Teacher-forced LSTMDecoder.forward in training mode (decoder.py:100-195) for input tokens
+ * (B,T) int32 [= formulas[:, :-1], seq2seq.py:115-120]; keeps what BPTT needs in `workspace`.
+ * dropout_p: nn.Dropout p (masks from a counter-based hash of `seed`; 0 disables);
+ * attention_path: 0 = decoder.py:121-143 (dropout on cat[emb,enc]), 1 = :144-193 (dropout on emb).
+ * logits_out (B,T,V). */
+size_t i2l_decoder_train_workspace_bytes(int B, int T, int vocab, int embed, int hidden, int layers);
+int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* enc, const int32_t* tokens, int B, int T,
+                          float dropout_p, uint64_t seed, int attention_path, void* workspace,
+                          size_t workspace_bytes, float* logits_out, i2l_stream_t stream);
+/* Backward of the above for a given dlogits (B,T,V): fills every gradient of `grads` (overwrite)
+ * and denc_out (B,E).  `workspace` must be the one the forward call filled. */
+int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t* tokens, int B, int T, float dropout_p,
+                          uint64_t seed, int attention_path, void* workspace, size_t workspace_bytes,
+                          const float* dlogits, const i2l_decoder_grads* grads, float* denc_out,
+                          i2l_stream_t stream);
+
+/* nn.CrossEntropyLoss(ignore_index=pad, label_smoothing=eps) over `rows` = B*T rows of logits (rows,V)
+ * (trainer.py:111-115,335-336).  loss_sum_and_count_out[0] = SUM over non-pad rows of the per-row loss,
+ * [1] = number of non-pad rows (loss = [0]/[1]); dlogits_out (rows,V) or NULL = gradient of the SUM
+ * (divide by the GLOBAL count after the data-parallel all-reduce). */
+size_t i2l_ce_workspace_bytes(int rows);
+int i2l_ce_label_smooth_fwd_bwd(const float* logits, const int32_t* targets, int rows, int vocab, int pad_id,
+                                float label_smoothing, void* workspace, size_t workspace_bytes,
+                                float* dlogits_out, float* loss_sum_and_count_out, i2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

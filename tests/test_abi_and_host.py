@@ -17,8 +17,7 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "img2latex_hip.h")).read()
-    declared = set(re.findall(r"\b(i2l_[a-z0-9_]+)\s*\(", header))
-    declared -= {"i2l_stream_t"}
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(i2l_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     handle = _lib.lib()                       # binds every symbol, AttributeError if one is missing
     assert handle.i2l_version() >= 100
