@@ -39,8 +39,10 @@ constexpr int M_ST = 48;                       // LDS row stride (floats), == 16
 constexpr int M_CH = M_IR * M_ST;              // 480 floats per staged channel
 
 // wpack[co_blk][chunk][cp][tap][h][CO_BLK]: value = w[co_blk*CO_BLK + co][chunk*CI_BLK + 2*cp + h][tap], 0 outside.
+// flip != 0 packs the weights of the DATA-GRADIENT convolution: w is the forward filter (Cin_f = Cout, Cout_f = Cin),
+// value = w[ci][co][2-ky][2-kx].
 __global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpack, int Cin, int Cout,
-                                         int ci_blk, int n_chunks, int CO_BLK, int total) {
+                                         int ci_blk, int n_chunks, int CO_BLK, int total, int flip) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int co_l = idx % CO_BLK;
@@ -51,13 +53,19 @@ __global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __r
     const int chunk = r % n_chunks;
     const int cb = r / n_chunks;
     const int co = cb * CO_BLK + co_l, ci = chunk * ci_blk + 2 * cp + h;
-    wpack[idx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+    float v = 0.f;
+    if (co < Cout && ci < Cin)
+        v = flip ? w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : w[((size_t)co * Cin + ci) * 9 + tap];
+    wpack[idx] = v;
 }
 
-template <int CI_BLK, int NTL>      // NTL = 32-channel N-tiles per wave (workgroup covers CO_BLK = 32*NTL channels)
+// POOL = true : y = maxpool2(relu(conv + bias)) (B,Cout,Hp,Wp), optional argmax (0..3 = 2*dy+dx, first max wins)
+// POOL = false: y = conv (B,Cout,H,W), no bias / activation (the data-gradient convolution of the backward pass)
+template <int CI_BLK, int NTL, bool POOL>      // NTL = 32-channel N-tiles per wave (workgroup covers CO_BLK = 32*NTL channels)
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
-    float* __restrict__ y, int Cin, int H, int W, int Cout, int Hp, int Wp, int tiles_x, int n_chunks) {
+    float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
+    int tiles_x, int n_chunks) {
     constexpr int CO_BLK = 32 * NTL;
     constexpr int W_SLAB = (CI_BLK / 2) * 9 * 2 * CO_BLK;          // floats of packed weights per chunk
     __shared__ __attribute__((aligned(16))) float in_s[CI_BLK * M_CH];
@@ -130,19 +138,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     for (int n = 0; n < NTL; ++n) {
         const int co = cb * CO_BLK + n * 32 + i;
         if (co >= Cout) continue;
-        const float bv = bias[co];
+        if (POOL) {
+            const float bv = bias[co];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int py = (y0 >> 1) + wy * 2 + m;
-            if (py >= Hp) continue;
-            float* yrow = y + (((size_t)b * Cout + co) * Hp + py) * Wp;
+            for (int m = 0; m < 2; ++m) {
+                const int py = (y0 >> 1) + wy * 2 + m;
+                if (py >= Hp) continue;
+                const size_t rowoff = (((size_t)b * Cout + co) * Hp + py) * Wp;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int px = (x0 >> 1) + wx * 8 + 2 * q + h;
-                const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
-                                      fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
-                if (px < Wp) yrow[px] = fmaxf(v, 0.f);
+                for (int q = 0; q < 4; ++q) {
+                    const int px = (x0 >> 1) + wx * 8 + 2 * q + h;
+                    float best = acc[m][n][4 * q];
+                    int bi = 0;
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (acc[m][n][4 * q + e] > best) { best = acc[m][n][4 * q + e]; bi = e; }
+                    if (px < Wp) {
+                        y[rowoff + px] = fmaxf(best + bv, 0.f);
+                        if (amax) amax[rowoff + px] = (unsigned char)bi;
+                    }
+                }
             }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;          // MFMA row -> (pp, dy, dx)
+                    const int yy = y0 + wy * 4 + m * 2 + ((ri >> 1) & 1);
+                    const int xx = x0 + wx * 16 + 2 * (ri >> 2) + (ri & 1);
+                    if (yy < H && xx < W) y[(((size_t)b * Cout + co) * H + yy) * W + xx] = acc[m][n][r];
+                }
         }
     }
 }
@@ -162,10 +188,12 @@ constexpr int TIW = 2 * TPW + 2;           // 66 input cols
 constexpr int TIWP = TIW + 2;              // padded row stride (68 floats: rows stay 8B aligned)
 constexpr int CI_T = 8;
 
-template <int CO_T>
+// flip != 0: data-gradient convolution, weight element = w[ci][co][2-ky][2-kx] (w is the forward filter).
+template <int CO_T, bool POOL>
 __global__ __launch_bounds__(256) void conv3x3_relu_pool2_direct(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ y, int B, int Cin, int H, int W, int Cout, int Hp, int Wp, int co_groups) {
+    float* __restrict__ y, unsigned char* __restrict__ amax, int B, int Cin, int H, int W, int Cout, int Hp, int Wp,
+    int co_groups, int flip) {
     __shared__ float tile[CI_T * TIH * TIWP];
     const int tid = threadIdx.x;
     const int px = tid & (TPW - 1), py = tid >> 5;
@@ -206,12 +234,13 @@ __global__ __launch_bounds__(256) void conv3x3_relu_pool2_direct(
 #pragma unroll
             for (int c = 0; c < CO_T; ++c) {
                 if (co0 + c < Cout) {                       // block-uniform
-                    const float* wp = w + ((size_t)(co0 + c) * Cin + (ci0 + ci)) * 9;
+                    const float* wp = flip ? w + ((size_t)(ci0 + ci) * Cout + (co0 + c)) * 9
+                                           : w + ((size_t)(co0 + c) * Cin + (ci0 + ci)) * 9;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            const float wv = wp[ky * 3 + kx];
+                            const float wv = flip ? wp[8 - (ky * 3 + kx)] : wp[ky * 3 + kx];
                             acc[c][0] = fmaf(in[ky][kx], wv, acc[c][0]);
                             acc[c][1] = fmaf(in[ky][kx + 1], wv, acc[c][1]);
                             acc[c][2] = fmaf(in[ky + 1][kx], wv, acc[c][2]);
@@ -222,12 +251,31 @@ __global__ __launch_bounds__(256) void conv3x3_relu_pool2_direct(
         }
     }
     const int PY = PY0 + py, PX = PX0 + px;
-    if (PY < Hp && PX < Wp) {
+    if (POOL) {
+        if (PY < Hp && PX < Wp) {
+#pragma unroll
+            for (int c = 0; c < CO_T; ++c) {
+                if (co0 + c < Cout) {
+                    float best = acc[c][0];
+                    int bi = 0;
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (acc[c][e] > best) { best = acc[c][e]; bi = e; }
+                    const size_t o = (((size_t)b * Cout + co0 + c) * Hp + PY) * Wp + PX;
+                    y[o] = fmaxf(best + bias[co0 + c], 0.f);
+                    if (amax) amax[o] = (unsigned char)bi;
+                }
+            }
+        }
+    } else {
 #pragma unroll
         for (int c = 0; c < CO_T; ++c) {
             if (co0 + c < Cout) {
-                float v = fmaxf(fmaxf(acc[c][0], acc[c][1]), fmaxf(acc[c][2], acc[c][3])) + bias[co0 + c];
-                y[(((size_t)b * Cout + co0 + c) * Hp + PY) * Wp + PX] = fmaxf(v, 0.f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int yy = 2 * PY + (e >> 1), xx = 2 * PX + (e & 1);
+                    if (yy < H && xx < W) y[(((size_t)b * Cout + co0 + c) * H + yy) * W + xx] = acc[c][e];
+                }
             }
         }
     }
@@ -237,11 +285,20 @@ int mfma_ci_blk(int Cin) { return Cin <= 4 ? 4 : 8; }
 int mfma_co_blk(int Cout) { return Cout % 64 == 0 ? 64 : 32; }
 
 template <int CI_BLK, int NTL>
-void launch_mfma(dim3 grid, hipStream_t s, const float* x, const float* wpack, const float* bias, float* y, int Cin,
-                 int H, int W, int Cout, int Hp, int Wp, int tiles_x, int n_chunks) {
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CI_BLK, NTL>), grid, dim3(256), 0, s, x, wpack, bias, y, Cin, H, W, Cout,
-                       Hp, Wp, tiles_x, n_chunks);
+void launch_mfma(bool pool, dim3 grid, hipStream_t s, const float* x, const float* wpack, const float* bias, float* y,
+                 unsigned char* amax, int Cin, int H, int W, int Cout, int Hp, int Wp, int tiles_x, int n_chunks) {
+    if (pool)
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<CI_BLK, NTL, true>), grid, dim3(256), 0, s, x, wpack, bias, y, amax, Cin,
+                           H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+    else
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<CI_BLK, NTL, false>), grid, dim3(256), 0, s, x, wpack, bias, y, amax,
+                           Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
 }
+
+// One 3x3 / pad 1 convolution launch.  pool: fused bias+ReLU+maxpool2 (+argmax); !pool: plain full-resolution
+// conv with the flipped/transposed filter (data gradient).  `wpack_ws` must hold i2l_conv_workspace_bytes().
+int run_conv(bool pool, const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B,
+             int Cin, int H, int W, int Cout, void* wpack_ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace
 
@@ -252,12 +309,11 @@ extern "C" size_t i2l_conv_workspace_bytes(int Cin, int Cout) {
     return i2l_align((size_t)co_blocks * n_chunks * (cb / 2) * 9 * 2 * cob * sizeof(float));
 }
 
-extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias, float* y,
-                                           int B, int Cin, int H, int W, int Cout, void* workspace,
-                                           size_t workspace_bytes, i2l_stream_t stream) {
-    if (!x || !w || !bias || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2) return I2L_ERR_ARG;
+namespace {
+
+int run_conv(bool pool, const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B,
+             int Cin, int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const int Hp = H / 2, Wp = W / 2;
-    hipStream_t s = i2l_s(stream);
     if (Cout % 32 == 0) {
         const size_t need = i2l_conv_workspace_bytes(Cin, Cout);
         if (!workspace || workspace_bytes < need) return I2L_ERR_WORKSPACE;
@@ -266,25 +322,178 @@ extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const 
         const int total = co_blocks * n_chunks * (cbk / 2) * 9 * 2 * cob;
         float* wpack = static_cast<float*>(workspace);
         hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(i2l_cdiv(total, 256)), dim3(256), 0, s, w, wpack, Cin, Cout,
-                           cbk, n_chunks, cob, total);
+                           cbk, n_chunks, cob, total, pool ? 0 : 1);
         I2L_CHECK_LAUNCH();
-        // tiles cover the conv positions that feed a pooled output (floor pooling drops an odd last row/col)
-        const int tiles_x = i2l_cdiv(2 * Wp, M_TC), tiles_y = i2l_cdiv(2 * Hp, M_TR);
+        // pooled: tiles cover the conv positions that feed a pooled output (floor pooling drops an odd last
+        // row/col); plain: every position
+        const int rows = pool ? 2 * Hp : H, cols = pool ? 2 * Wp : W;
+        const int tiles_x = i2l_cdiv(cols, M_TC), tiles_y = i2l_cdiv(rows, M_TR);
         if ((long long)tiles_x * tiles_y > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
         dim3 grid(co_blocks, tiles_x * tiles_y, B);
-        if (cbk == 4 && cob == 32) launch_mfma<4, 1>(grid, s, x, wpack, bias, y, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
-        else if (cbk == 4) launch_mfma<4, 2>(grid, s, x, wpack, bias, y, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
-        else if (cob == 32) launch_mfma<8, 1>(grid, s, x, wpack, bias, y, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
-        else launch_mfma<8, 2>(grid, s, x, wpack, bias, y, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+        if (cbk == 4 && cob == 32) launch_mfma<4, 1>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+        else if (cbk == 4) launch_mfma<4, 2>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+        else if (cob == 32) launch_mfma<8, 1>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+        else launch_mfma<8, 2>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
         I2L_CHECK_LAUNCH();
         return I2L_OK;
     }
     constexpr int CO_T = 8;
     const int co_groups = i2l_cdiv(Cout, CO_T);
-    if (i2l_cdiv(Wp, TPW) > 65535 || i2l_cdiv(Hp, TPH) > 65535) return I2L_ERR_UNSUPPORTED;
-    dim3 grid(B * co_groups, i2l_cdiv(Wp, TPW), i2l_cdiv(Hp, TPH));
-    hipLaunchKernelGGL(conv3x3_relu_pool2_direct<CO_T>, grid, dim3(256), 0, s, x, w, bias, y, B, Cin, H, W, Cout,
-                       Hp, Wp, co_groups);
+    // the direct kernel walks 2x2 quads: ceil so that an odd last row/col is produced in the plain mode
+    const int qh = pool ? Hp : i2l_cdiv(H, 2), qw = pool ? Wp : i2l_cdiv(W, 2);
+    if (i2l_cdiv(qw, TPW) > 65535 || i2l_cdiv(qh, TPH) > 65535) return I2L_ERR_UNSUPPORTED;
+    dim3 grid(B * co_groups, i2l_cdiv(qw, TPW), i2l_cdiv(qh, TPH));
+    if (pool)
+        hipLaunchKernelGGL((conv3x3_relu_pool2_direct<CO_T, true>), grid, dim3(256), 0, s, x, w, bias, y, amax, B, Cin,
+                           H, W, Cout, Hp, Wp, co_groups, 0);
+    else
+        hipLaunchKernelGGL((conv3x3_relu_pool2_direct<CO_T, false>), grid, dim3(256), 0, s, x, w, bias, y, amax, B, Cin,
+                           H, W, Cout, Hp, Wp, co_groups, 1);
     I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+}  // namespace
+
+extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias, float* y,
+                                           unsigned char* argmax_out, int B, int Cin, int H, int W, int Cout,
+                                           void* workspace, size_t workspace_bytes, i2l_stream_t stream) {
+    if (!x || !w || !bias || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2) return I2L_ERR_ARG;
+    return run_conv(true, x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of one block
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// dyp (B,C,H,W) = gradient w.r.t. the conv output: the pooled gradient goes to the window's argmax
+// position if the pooled (post-ReLU) output is positive, everything else is 0 (ReLU' and MaxPool').
+__global__ __launch_bounds__(256) void unpool_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const unsigned char* __restrict__ amax,
+                                                              float* __restrict__ dyp, size_t planes, int H, int W,
+                                                              int Hp, int Wp) {
+    const size_t total = planes * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pl = i / ((size_t)H * W);
+        const int rem = (int)(i - pl * H * W);
+        const int yy = rem / W, xx = rem - yy * W;
+        const int py = yy >> 1, px = xx >> 1;
+        float v = 0.f;
+        if (py < Hp && px < Wp) {
+            const size_t o = (pl * Hp + py) * Wp + px;
+            if (y[o] > 0.f && (int)amax[o] == 2 * (yy & 1) + (xx & 1)) v = dy[o];
+        }
+        dyp[i] = v;
+    }
+}
+
+// colT[b][(ci*9+tap)][pos] = x[b][ci][y+ky-1][x+kx-1] (0 outside) for a chunk of images
+__global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ x, float* __restrict__ colT, int nb,
+                                                       int Cin, int H, int W) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)nb * Cin * 9 * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / HW;                     // (b, ci, tap)
+        const int pos = (int)(i - row * HW);
+        const int tap = (int)(row % 9);
+        const size_t bc = row / 9;                     // b*Cin + ci
+        const int yy = pos / W + tap / 3 - 1, xx = pos % W + tap % 3 - 1;
+        colT[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(bc * H + yy) * W + xx] : 0.f;
+    }
+}
+
+// db[c] = sum_{b,pos} dyp[b][c][pos]: one workgroup per channel, fixed order.
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ dyp, float* __restrict__ db, int B,
+                                                        int C, size_t HW) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* p = dyp + ((size_t)b * C + c) * HW;
+        for (size_t i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] = (float)red[0];
+}
+
+constexpr int WG_CHUNK = 32;    // images per weight-gradient GEMM call
+
+struct BwdLayout { size_t dyp, colT, gemm, wpack, total; size_t gemm_bytes, wpack_bytes; int chunk; };
+
+BwdLayout bwd_layout(int B, int Cin, int H, int W, int Cout) {
+    BwdLayout o{};
+    const size_t HW = (size_t)H * W;
+    o.chunk = B < WG_CHUNK ? B : WG_CHUNK;
+    size_t off = 0;
+    o.dyp = off; off += i2l_align((size_t)B * Cout * HW * sizeof(float));
+    o.colT = off; off += i2l_align((size_t)o.chunk * Cin * 9 * HW * sizeof(float));
+    o.gemm_bytes = i2l_gemm_workspace_bytes(Cout, Cin * 9, (int)HW, o.chunk);
+    o.gemm = off; off += i2l_align(o.gemm_bytes);
+    o.wpack_bytes = i2l_conv_workspace_bytes(Cout, Cin);         // data-gradient conv: Cout -> Cin channels
+    o.wpack = off; off += i2l_align(o.wpack_bytes);
+    o.total = off;
+    return o;
+}
+
+}  // namespace
+
+extern "C" size_t i2l_conv_bwd_workspace_bytes(int B, int Cin, int H, int W, int Cout) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2) return 0;
+    return bwd_layout(B, Cin, H, W, Cout).total;
+}
+
+extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const float* y, const uint8_t* argmax,
+                                           const float* dy, float* dx, float* dw, float* db, int B, int Cin, int H,
+                                           int W, int Cout, void* workspace, size_t workspace_bytes,
+                                           i2l_stream_t stream) {
+    if (!x || !w || !y || !argmax || !dy || !dw || !db || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2)
+        return I2L_ERR_ARG;
+    const BwdLayout lo = bwd_layout(B, Cin, H, W, Cout);
+    if (!workspace || workspace_bytes < lo.total) return I2L_ERR_WORKSPACE;
+    char* base = static_cast<char*>(workspace);
+    float* dyp = reinterpret_cast<float*>(base + lo.dyp);
+    float* colT = reinterpret_cast<float*>(base + lo.colT);
+    hipStream_t s = i2l_s(stream);
+    const int Hp = H / 2, Wp = W / 2;
+    const size_t HW = (size_t)H * W;
+    {
+        const size_t total = (size_t)B * Cout * HW;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(unpool_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, y, argmax, dyp,
+                           (size_t)B * Cout, H, W, Hp, Wp);
+        I2L_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(Cout), dim3(256), 0, s, (const float*)dyp, db, B, Cout, HW);
+    I2L_CHECK_LAUNCH();
+    // weight gradient: dw[co][(ci,tap)] = sum_b sum_pos dyp[b][co][pos] * colT[b][(ci,tap)][pos]
+    for (int b0 = 0; b0 < B; b0 += lo.chunk) {
+        const int nb = B - b0 < lo.chunk ? B - b0 : lo.chunk;
+        const size_t total = (size_t)nb * Cin * 9 * HW;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x + (size_t)b0 * Cin * HW, colT, nb,
+                           Cin, H, W);
+        I2L_CHECK_LAUNCH();
+        GemmArgs g = gemm_args();
+        g.A = dyp + (size_t)b0 * Cout * HW; g.lda = (long)HW; g.bsa = (long)(Cout * HW);
+        g.W = colT; g.ldw = (long)HW; g.bsw = (long)(Cin * 9 * HW);
+        g.nz = nb;
+        g.C = dw; g.ldc = Cin * 9;
+        g.M = Cout; g.N = Cin * 9; g.K = (int)HW;
+        g.accumulate = b0 > 0 ? 1 : 0;
+        const int rc = i2l_gemm(g, base + lo.gemm, lo.gemm_bytes, s);
+        if (rc != I2L_OK) return rc;
+    }
+    if (dx) {   // data gradient = conv3x3(dyp, flipped / transposed filter), Cout -> Cin channels
+        const int rc = run_conv(false, dyp, w, nullptr, dx, nullptr, B, Cout, H, W, Cin, base + lo.wpack, lo.wpack_bytes, s);
+        if (rc != I2L_OK) return rc;
+    }
     return I2L_OK;
 }

@@ -218,3 +218,70 @@ extern "C" int i2l_linear_bias_act_fwd(const float* x, const float* w, const flo
     g.relu = relu ? 1 : 0;
     return i2l_gemm(g, workspace, workspace_bytes, i2l_s(stream));
 }
+
+// ---------------------------------------------------------------- backward of y = act(x W^T + b)
+namespace {
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ A, int M, int N,
+                                                           float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += A[(size_t)m * N + n];
+    out[n] = s;
+}
+size_t lin_bwd_gemm_ws(int M, int K, int N) {
+    const size_t a = i2l_gemm_workspace_bytes(N, K, M), b = i2l_gemm_workspace_bytes(M, K, N);
+    return i2l_align(a > b ? a : b);
+}
+}  // namespace
+
+extern "C" size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return i2l_align((size_t)M * N * sizeof(float)) + lin_bwd_gemm_ws(M, K, N);
+}
+
+extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                                        float* dw, float* db, int M, int K, int N, int relu, void* workspace,
+                                        size_t workspace_bytes, i2l_stream_t stream) {
+    if (!x || !w || !dy || !dw || !db || (relu && !y) || M <= 0 || K <= 0 || N <= 0) return I2L_ERR_ARG;
+    if (!workspace || workspace_bytes < i2l_linear_bwd_workspace_bytes(M, K, N)) return I2L_ERR_WORKSPACE;
+    hipStream_t s = i2l_s(stream);
+    float* dpre = static_cast<float*>(workspace);
+    char* gws = static_cast<char*>(workspace) + i2l_align((size_t)M * N * sizeof(float));
+    const size_t gws_bytes = lin_bwd_gemm_ws(M, K, N);
+    const float* d = dy;
+    if (relu) {
+        const size_t n = (size_t)M * N;
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, y, dpre, n);
+        I2L_CHECK_LAUNCH();
+        d = dpre;
+    }
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(i2l_cdiv(N, 256)), dim3(256), 0, s, d, M, N, db);
+    I2L_CHECK_LAUNCH();
+    {   // dw[n][k] = sum_m d[m][n] * x[m][k]
+        GemmArgs g = gemm_args();
+        g.A = d; g.lda = N; g.a_kc = 0;
+        g.W = x; g.ldw = K; g.w_kc = 0;
+        g.C = dw; g.ldc = K;
+        g.M = N; g.N = K; g.K = M;
+        const int rc = i2l_gemm(g, gws, gws_bytes, s);
+        if (rc != I2L_OK) return rc;
+    }
+    if (dx) {   // dx[m][k] = sum_n d[m][n] * w[n][k]
+        GemmArgs g = gemm_args();
+        g.A = d; g.lda = N;
+        g.W = w; g.ldw = K; g.w_kc = 0;
+        g.C = dx; g.ldc = K;
+        g.M = M; g.N = K; g.K = N;
+        const int rc = i2l_gemm(g, gws, gws_bytes, s);
+        if (rc != I2L_OK) return rc;
+    }
+    return I2L_OK;
+}

@@ -39,8 +39,14 @@ _SIGNATURES = {
     "i2l_version": (c_int, []),
     "i2l_error_string": (c_char_p, [c_int]),
     "i2l_conv_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "i2l_conv3x3_relu_pool2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                           c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_conv3x3_relu_pool2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_conv_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "i2l_conv3x3_relu_pool2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_linear_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "i2l_linear_bias_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "i2l_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "i2l_linear_bias_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p, c_size_t, c_void_p]),

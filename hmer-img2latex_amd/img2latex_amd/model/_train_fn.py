@@ -66,3 +66,56 @@ class DecoderTeacherForcedFn(torch.autograd.Function):
         del keep
         ctx.ws = None
         return (None, denc, None, None) + tuple(grads[n] for n, _ in named)
+
+
+class CNNEncoderFn(torch.autograd.Function):
+    """CNNEncoder.forward with a HIP backward (autograd of encoder.py:111-129).
+
+    inputs: encoder module, images, then the parameters in ``encoder.parameters()`` order
+    (conv weight/bias per block, embedding_layer weight/bias)."""
+
+    @staticmethod
+    def forward(ctx, encoder, x, *params):
+        x = _lib.require_gpu(x.detach(), "images")
+        amax, blocks = [], []
+        out = encoder._forward_impl(x, argmax_out=amax, blocks_out=blocks)
+        ctx.encoder, ctx.x, ctx.blocks, ctx.amax, ctx.out = encoder, x, blocks, amax, out
+        ctx.need_dx = False
+        return out
+
+    @staticmethod
+    def backward(ctx, denc):
+        enc = ctx.encoder
+        L = _lib.lib()
+        denc = _lib.require_gpu(denc, "d encoder_output")
+        dev = denc.device
+        named = list(enc.named_parameters())
+        grads = {n: torch.empty_like(p_) for n, p_ in named}
+        feat = ctx.blocks[-1]
+        B = feat.shape[0]
+        K, E = feat.numel() // B, enc.embedding_dim
+        lin = enc.embedding_layer
+        dfeat = torch.empty_like(feat)
+        nbytes = L.i2l_linear_bwd_workspace_bytes(B, K, E)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.i2l_linear_bias_act_bwd(feat.data_ptr(), lin.weight.detach().data_ptr(), ctx.out.data_ptr(),
+                                             denc.data_ptr(), dfeat.data_ptr(), grads["embedding_layer.weight"].data_ptr(),
+                                             grads["embedding_layer.bias"].data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
+                                             _lib.stream_ptr()), "linear_bias_act_bwd")
+        dy = dfeat
+        nblk = len(enc.conv_filters)
+        for i in reversed(range(nblk)):
+            conv = enc.cnn_layers[3 * i]
+            xin = ctx.x if i == 0 else ctx.blocks[i - 1]
+            _, cin, h, w = xin.shape
+            dx = torch.empty_like(xin) if i > 0 else None          # images need no gradient
+            nbytes = L.i2l_conv_bwd_workspace_bytes(B, cin, h, w, conv.out_channels)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.i2l_conv3x3_relu_pool2_bwd(
+                xin.data_ptr(), conv.weight.detach().data_ptr(), ctx.blocks[i].data_ptr(), ctx.amax[i].data_ptr(),
+                dy.data_ptr(), _lib.ptr(dx), grads[f"cnn_layers.{3 * i}.weight"].data_ptr(),
+                grads[f"cnn_layers.{3 * i}.bias"].data_ptr(), B, cin, h, w, conv.out_channels, ws.data_ptr(), nbytes,
+                _lib.stream_ptr()), "conv3x3_relu_pool2_bwd")
+            dy = dx
+        ctx.blocks = ctx.amax = None
+        return (None, None) + tuple(grads[n] for n, _ in named)

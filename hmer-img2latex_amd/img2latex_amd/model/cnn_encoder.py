@@ -58,10 +58,9 @@ class CNNEncoder(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
-    def conv_blocks(self, x: torch.Tensor) -> List[torch.Tensor]:
-        """Outputs of the conv blocks (each = Conv2d+ReLU+MaxPool2d fused in one launch)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("img2latex_amd: encoder backward is not built yet (use torch.no_grad())")
+    def conv_blocks(self, x: torch.Tensor, argmax_out: Optional[List[torch.Tensor]] = None) -> List[torch.Tensor]:
+        """Outputs of the conv blocks (each = Conv2d+ReLU+MaxPool2d fused in one launch).
+        ``argmax_out``: a list that receives the uint8 pooling-argmax maps (training forward)."""
         x = _lib.require_gpu(x, "images")
         if x.dim() != 4 or x.shape[1] != self.channels:
             raise RuntimeError(f"expected (B,{self.channels},H,W) images, got {tuple(x.shape)}")
@@ -76,9 +75,13 @@ class CNNEncoder(nn.Module):
             bs = _lib.require_gpu(conv.bias.detach(), "conv bias")
             nbytes = L.i2l_conv_workspace_bytes(cin, conv.out_channels)
             ws = self._workspace(nbytes, x.device)
+            amax = None
+            if argmax_out is not None:
+                amax = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+                argmax_out.append(amax)
             _lib.check(L.i2l_conv3x3_relu_pool2_fwd(x.data_ptr(), wt.data_ptr(), bs.data_ptr(), y.data_ptr(),
-                                                    B, cin, h, w, conv.out_channels, _lib.ptr(ws), nbytes,
-                                                    _lib.stream_ptr()),
+                                                    _lib.ptr(amax), B, cin, h, w, conv.out_channels, _lib.ptr(ws),
+                                                    nbytes, _lib.stream_ptr()),
                        "conv3x3_relu_pool2_fwd")
             _lib.mark(f"conv{i}")
             outs.append(y)
@@ -86,8 +89,14 @@ class CNNEncoder(nn.Module):
         return outs
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """(B,C,H,W) -> (B,E)   (encoder.py:111-129)."""
-        feat = self.conv_blocks(x)[-1]
+        """(B,C,H,W) -> (B,E)   (encoder.py:111-129).  With gradients enabled the result carries a
+        grad_fn whose backward runs the HIP gradient kernels."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ._train_fn import CNNEncoderFn
+            return CNNEncoderFn.apply(self, x, *self.parameters())
+        return self._forward_impl(x)
+
+    def _linear(self, feat: torch.Tensor) -> torch.Tensor:
         B = feat.shape[0]
         K = feat.numel() // B                           # Flatten: NCHW row-major, a view
         if K != self.embedding_layer.in_features:
@@ -105,3 +114,10 @@ class CNNEncoder(nn.Module):
                    "linear_bias_act_fwd")
         _lib.mark("fc")
         return out
+
+    def _forward_impl(self, x: torch.Tensor, argmax_out: Optional[List[torch.Tensor]] = None,
+                      blocks_out: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        blocks = self.conv_blocks(x, argmax_out)
+        if blocks_out is not None:
+            blocks_out.extend(blocks)
+        return self._linear(blocks[-1])

@@ -50,9 +50,19 @@ const char* i2l_error_string(int code);
  * Replaces nn.Conv2d + nn.ReLU + nn.MaxPool2d, encoder.py:78-95 executed at :122.
  * x (B,Cin,H,W)  w (Cout,Cin,3,3)  bias (Cout)  y (B,Cout,H/2,W/2), NCHW fp32. */
 size_t i2l_conv_workspace_bytes(int Cin, int Cout);   /* packed-weight scratch; 0 when none is needed */
+/* argmax_out: NULL, or (B,Cout,H/2,W/2) uint8 receiving the position 2*dy+dx of each pooling
+ * window's maximum (first maximum wins, as ATen) -- what the backward pass needs. */
 int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias, float* y,
-                               int B, int Cin, int H, int W, int Cout, void* workspace,
+                               uint8_t* argmax_out, int B, int Cin, int H, int W, int Cout, void* workspace,
                                size_t workspace_bytes, i2l_stream_t stream);
+
+/* Backward of one CNN block (autograd of encoder.py:78-95 under loss.backward(), trainer.py:337):
+ * given dy (B,Cout,H/2,W/2), the block's input x, output y and pooling argmax, computes
+ * dw (Cout,Cin,3,3), db (Cout) and, unless dx is NULL, dx (B,Cin,H,W).  Gradients are overwritten. */
+size_t i2l_conv_bwd_workspace_bytes(int B, int Cin, int H, int W, int Cout);
+int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const float* y, const uint8_t* argmax,
+                               const float* dy, float* dx, float* dw, float* db, int B, int Cin, int H,
+                               int W, int Cout, void* workspace, size_t workspace_bytes, i2l_stream_t stream);
 
 /* y = act(x @ w^T + bias): nn.Flatten + nn.Linear + nn.ReLU, encoder.py:105-107,125-127
  * (also nn.Linear(Hd->V), decoder.py:90).  x (M,K)  w (N,K)  bias (N) or NULL  y (M,N).
@@ -61,6 +71,12 @@ size_t i2l_linear_workspace_bytes(int M, int K, int N);
 int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, float* y,
                             int M, int K, int N, int relu, void* workspace, size_t workspace_bytes,
                             i2l_stream_t stream);
+/* Backward of the above: dy (M,N) -> dx (M,K) (or NULL), dw (N,K), db (N); with relu != 0 the
+ * gradient is first masked by y > 0.  Gradients are overwritten. */
+size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N);
+int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                            float* dw, float* db, int M, int K, int N, int relu, void* workspace,
+                            size_t workspace_bytes, i2l_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Decoder (reference img2latex/model/decoder.py, seq2seq.py, predictor.py)

@@ -195,14 +195,14 @@ def test_conv_kernel_odd_shapes():
         nbytes = L.i2l_conv_workspace_bytes(Cin, Cout)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
         rc = L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(),
-                                          y.data_ptr(), B, Cin, H, W, Cout, ws.data_ptr(), nbytes, _lib.stream_ptr())
+                                          y.data_ptr(), None, B, Cin, H, W, Cout, ws.data_ptr(), nbytes, _lib.stream_ptr())
         assert rc == 0
         close(y.cpu().numpy(), want.numpy(), 1e-5)
 
 
 def test_error_codes_not_exceptions():
     L = _lib.lib()
-    assert L.i2l_conv3x3_relu_pool2_fwd(None, None, None, None, 1, 1, 4, 4, 1, None, 0, None) == -1
+    assert L.i2l_conv3x3_relu_pool2_fwd(None, None, None, None, None, 1, 1, 4, 4, 1, None, 0, None) == -1
     assert L.i2l_linear_bias_act_fwd(None, None, None, None, 1, 1, 1, 0, None, 0, None) == -1
 
 

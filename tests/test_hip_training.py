@@ -85,3 +85,49 @@ def test_ce_kernel_vs_torch():
         assert abs(float(got[0]) - float(loss)) <= 1e-5 * abs(float(loss))
         assert int(got[1]) == int((tgt != PAD).sum())
         rel_close(dl.cpu().numpy(), ref_logits.grad.numpy(), 1e-5, "dlogits")
+
+
+@pytest.mark.parametrize("name", SMALL + ["primary"])
+def test_encoder_backward_vs_oracle(name):
+    """d(sum(enc * r))/d(encoder params) against the oracle's autograd."""
+    d, cfg, m = build(name)
+    sd = torch_state_dict(name)
+    x = images(cfg)
+    r = torch.from_numpy(synth.uniform(5, "probe", (4, cfg["embedding_dim"]), -1.0, 1.0))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    enc_cpu = O.cnn_encoder({**sd, **params}, cfg, x)
+    (enc_cpu * r).sum().backward()
+    m.train()
+    enc = m.encoder(x.to(DEV))
+    rel_close(enc.detach().cpu().numpy(), enc_cpu.detach().numpy(), 1e-5, "enc")
+    (enc * r.to(DEV)).sum().backward()
+    for n, p in m.encoder.named_parameters():
+        rel_close(p.grad.cpu().numpy(), params["encoder." + n].grad.numpy(), 3e-4, n)
+
+
+def test_conv_bwd_odd_shapes():
+    torch.manual_seed(2)
+    L = _lib.lib()
+    for (B, Cin, H, W, Cout) in [(2, 3, 7, 9, 5), (3, 5, 16, 70, 9), (2, 8, 12, 20, 32), (1, 32, 16, 48, 64), (2, 33, 9, 11, 96)]:
+        x = torch.randn(B, Cin, H, W, requires_grad=True)
+        w = (torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)).requires_grad_(True)
+        b = torch.randn(Cout, requires_grad=True)
+        y = O.conv_block(x, w, b)
+        dy = torch.randn_like(y)
+        (y * dy).sum().backward()
+        xd, wd, bd, dyd = x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV), dy.to(DEV)
+        yd = torch.empty(y.shape, device=DEV)
+        am = torch.empty(y.shape, dtype=torch.uint8, device=DEV)
+        nb = L.i2l_conv_workspace_bytes(Cin, Cout)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+        assert L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), am.data_ptr(), B,
+                                            Cin, H, W, Cout, ws.data_ptr(), nb, _lib.stream_ptr()) == 0
+        dx, dw, db = torch.empty_like(xd), torch.empty_like(wd), torch.empty_like(bd)
+        nb2 = L.i2l_conv_bwd_workspace_bytes(B, Cin, H, W, Cout)
+        ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
+        assert L.i2l_conv3x3_relu_pool2_bwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), am.data_ptr(), dyd.data_ptr(),
+                                            dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout,
+                                            ws2.data_ptr(), nb2, _lib.stream_ptr()) == 0
+        rel_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, "dx")
+        rel_close(dw.cpu().numpy(), w.grad.numpy(), 2e-4, "dw")
+        rel_close(db.cpu().numpy(), b.grad.numpy(), 2e-4, "db")
