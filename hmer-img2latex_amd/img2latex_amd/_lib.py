@@ -65,6 +65,10 @@ _SIGNATURES = {
                                       c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "i2l_decoder_train_bwd": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_float, c_uint64, c_int,
                                       c_void_p, c_size_t, c_void_p, POINTER(DecoderGrads), c_void_p, c_void_p]),
+    "i2l_optimizer_workspace_bytes": (c_size_t, []),
+    "i2l_grad_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
+                                        c_float, c_float, c_float, c_float, c_int, c_void_p, c_size_t, c_void_p,
+                                        c_void_p]),
     "i2l_ce_workspace_bytes": (c_size_t, [c_int]),
     "i2l_ce_label_smooth_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t,
                                             c_void_p, c_void_p, c_void_p]),

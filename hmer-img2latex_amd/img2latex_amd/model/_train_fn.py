@@ -22,50 +22,67 @@ class DecoderTeacherForcedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, decoder, enc, tokens, seed, *params):
-        enc = _lib.require_gpu(enc.detach(), "encoder_output")
-        tokens = _lib.require_gpu(tokens, "tokens", torch.int32)
-        B, T = tokens.shape
-        L = _lib.lib()
-        w, keep = decoder._weights_struct()
-        nbytes = L.i2l_decoder_train_workspace_bytes(B, T, decoder.vocab_size, decoder.embedding_dim,
-                                                     decoder.hidden_dim, decoder.lstm_layers)
-        if nbytes == 0:
-            raise RuntimeError("img2latex_amd: decoder dimensions not supported by the HIP training kernels")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
-        logits = torch.empty((B, T, decoder.vocab_size), dtype=torch.float32, device=enc.device)
-        p = float(decoder.dropout) if decoder.training else 0.0
-        _lib.check(L.i2l_decoder_train_fwd(ctypes.byref(w), enc.data_ptr(), tokens.data_ptr(), B, T, p, int(seed),
-                                           1 if decoder.use_attention else 0, ws.data_ptr(), nbytes,
-                                           logits.data_ptr(), _lib.stream_ptr()), "decoder_train_fwd")
-        del keep
-        ctx.decoder, ctx.ws, ctx.tokens, ctx.seed, ctx.p = decoder, ws, tokens, int(seed), p
-        ctx.enc_shape = enc.shape
+        logits, state = decoder_train_forward(decoder, enc.detach(), tokens, seed)
+        ctx.decoder, ctx.state = decoder, state
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         dec = ctx.decoder
-        dlogits = _lib.require_gpu(dlogits, "dlogits")
-        B, T = ctx.tokens.shape
-        L = _lib.lib()
-        w, keep = dec._weights_struct()
         named = list(dec.named_parameters())
-        grads = {n: torch.zeros_like(p_) if n.startswith("attention.") else torch.empty_like(p_) for n, p_ in named}
-        Ln = dec.lstm_layers
-        arrs = {k: _lib.pointer_array([grads[f"lstm.{k}_l{l}"] for l in range(Ln)])
-                for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
-        g = _lib.DecoderGrads()
-        g.embedding = grads["embedding.weight"].data_ptr()
-        g.w_ih, g.w_hh, g.b_ih, g.b_hh = arrs["weight_ih"], arrs["weight_hh"], arrs["bias_ih"], arrs["bias_hh"]
-        g.w_out, g.b_out = grads["output_layer.weight"].data_ptr(), grads["output_layer.bias"].data_ptr()
-        denc = torch.empty(ctx.enc_shape, dtype=torch.float32, device=dlogits.device)
-        _lib.check(L.i2l_decoder_train_bwd(ctypes.byref(w), ctx.tokens.data_ptr(), B, T, ctx.p, ctx.seed,
-                                           1 if dec.use_attention else 0, ctx.ws.data_ptr(), ctx.ws.numel(),
-                                           dlogits.data_ptr(), ctypes.byref(g), denc.data_ptr(), _lib.stream_ptr()),
-                   "decoder_train_bwd")
-        del keep
-        ctx.ws = None
+        grads = {n: torch.empty_like(p_) for n, p_ in named}
+        denc = decoder_train_backward(dec, ctx.state, dlogits, grads)
+        ctx.state = None
         return (None, denc, None, None) + tuple(grads[n] for n, _ in named)
+
+
+def decoder_train_forward(decoder, enc, tokens, seed):
+    """i2l_decoder_train_fwd: returns (logits (B,T,V), saved state for decoder_train_backward)."""
+    enc = _lib.require_gpu(enc, "encoder_output")
+    tokens = _lib.require_gpu(tokens, "tokens", torch.int32)
+    B, T = tokens.shape
+    L = _lib.lib()
+    w, keep = decoder._weights_struct()
+    nbytes = L.i2l_decoder_train_workspace_bytes(B, T, decoder.vocab_size, decoder.embedding_dim,
+                                                 decoder.hidden_dim, decoder.lstm_layers)
+    if nbytes == 0:
+        raise RuntimeError("img2latex_amd: decoder dimensions not supported by the HIP training kernels")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+    logits = torch.empty((B, T, decoder.vocab_size), dtype=torch.float32, device=enc.device)
+    p = float(decoder.dropout) if decoder.training else 0.0
+    _lib.check(L.i2l_decoder_train_fwd(ctypes.byref(w), enc.data_ptr(), tokens.data_ptr(), B, T, p, int(seed),
+                                       1 if decoder.use_attention else 0, ws.data_ptr(), nbytes,
+                                       logits.data_ptr(), _lib.stream_ptr()), "decoder_train_fwd")
+    del keep
+    return logits, dict(ws=ws, tokens=tokens, seed=int(seed), p=p, enc_shape=tuple(enc.shape))
+
+
+def decoder_train_backward(dec, state, dlogits, grads):
+    """i2l_decoder_train_bwd: fills ``grads`` (name -> tensor, ``decoder.named_parameters()`` names;
+    attention parameters are zero-filled) and returns d(encoder_output)."""
+    dlogits = _lib.require_gpu(dlogits, "dlogits")
+    tokens = state["tokens"]
+    B, T = tokens.shape
+    L = _lib.lib()
+    w, keep = dec._weights_struct()
+    for n, t in grads.items():
+        if n.startswith("attention."):
+            t.zero_()
+    Ln = dec.lstm_layers
+    arrs = {k: _lib.pointer_array([grads[f"lstm.{k}_l{l}"] for l in range(Ln)])
+            for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+    g = _lib.DecoderGrads()
+    g.embedding = grads["embedding.weight"].data_ptr()
+    g.w_ih, g.w_hh, g.b_ih, g.b_hh = arrs["weight_ih"], arrs["weight_hh"], arrs["bias_ih"], arrs["bias_hh"]
+    g.w_out, g.b_out = grads["output_layer.weight"].data_ptr(), grads["output_layer.bias"].data_ptr()
+    denc = torch.empty(state["enc_shape"], dtype=torch.float32, device=dlogits.device)
+    ws = state["ws"]
+    _lib.check(L.i2l_decoder_train_bwd(ctypes.byref(w), tokens.data_ptr(), B, T, state["p"], state["seed"],
+                                       1 if dec.use_attention else 0, ws.data_ptr(), ws.numel(),
+                                       dlogits.data_ptr(), ctypes.byref(g), denc.data_ptr(), _lib.stream_ptr()),
+               "decoder_train_bwd")
+    del keep
+    return denc
 
 
 class CNNEncoderFn(torch.autograd.Function):
@@ -76,46 +93,55 @@ class CNNEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, encoder, x, *params):
-        x = _lib.require_gpu(x.detach(), "images")
-        amax, blocks = [], []
-        out = encoder._forward_impl(x, argmax_out=amax, blocks_out=blocks)
-        ctx.encoder, ctx.x, ctx.blocks, ctx.amax, ctx.out = encoder, x, blocks, amax, out
-        ctx.need_dx = False
+        out, state = encoder_train_forward(encoder, x.detach())
+        ctx.encoder, ctx.state = encoder, state
         return out
 
     @staticmethod
     def backward(ctx, denc):
         enc = ctx.encoder
-        L = _lib.lib()
-        denc = _lib.require_gpu(denc, "d encoder_output")
-        dev = denc.device
         named = list(enc.named_parameters())
         grads = {n: torch.empty_like(p_) for n, p_ in named}
-        feat = ctx.blocks[-1]
-        B = feat.shape[0]
-        K, E = feat.numel() // B, enc.embedding_dim
-        lin = enc.embedding_layer
-        dfeat = torch.empty_like(feat)
-        nbytes = L.i2l_linear_bwd_workspace_bytes(B, K, E)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(L.i2l_linear_bias_act_bwd(feat.data_ptr(), lin.weight.detach().data_ptr(), ctx.out.data_ptr(),
-                                             denc.data_ptr(), dfeat.data_ptr(), grads["embedding_layer.weight"].data_ptr(),
-                                             grads["embedding_layer.bias"].data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
-                                             _lib.stream_ptr()), "linear_bias_act_bwd")
-        dy = dfeat
-        nblk = len(enc.conv_filters)
-        for i in reversed(range(nblk)):
-            conv = enc.cnn_layers[3 * i]
-            xin = ctx.x if i == 0 else ctx.blocks[i - 1]
-            _, cin, h, w = xin.shape
-            dx = torch.empty_like(xin) if i > 0 else None          # images need no gradient
-            nbytes = L.i2l_conv_bwd_workspace_bytes(B, cin, h, w, conv.out_channels)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _lib.check(L.i2l_conv3x3_relu_pool2_bwd(
-                xin.data_ptr(), conv.weight.detach().data_ptr(), ctx.blocks[i].data_ptr(), ctx.amax[i].data_ptr(),
-                dy.data_ptr(), _lib.ptr(dx), grads[f"cnn_layers.{3 * i}.weight"].data_ptr(),
-                grads[f"cnn_layers.{3 * i}.bias"].data_ptr(), B, cin, h, w, conv.out_channels, ws.data_ptr(), nbytes,
-                _lib.stream_ptr()), "conv3x3_relu_pool2_bwd")
-            dy = dx
-        ctx.blocks = ctx.amax = None
+        encoder_train_backward(enc, ctx.state, denc, grads)
+        ctx.state = None
         return (None, None) + tuple(grads[n] for n, _ in named)
+
+
+def encoder_train_forward(encoder, x):
+    x = _lib.require_gpu(x, "images")
+    amax, blocks = [], []
+    out = encoder._forward_impl(x, argmax_out=amax, blocks_out=blocks)
+    return out, dict(x=x, blocks=blocks, amax=amax, out=out)
+
+
+def encoder_train_backward(enc, state, denc, grads):
+    """Fills ``grads`` (``encoder.named_parameters()`` names) from d(encoder_output)."""
+    L = _lib.lib()
+    denc = _lib.require_gpu(denc, "d encoder_output")
+    dev = denc.device
+    blocks, amax = state["blocks"], state["amax"]
+    feat = blocks[-1]
+    B = feat.shape[0]
+    K, E = feat.numel() // B, enc.embedding_dim
+    lin = enc.embedding_layer
+    dfeat = torch.empty_like(feat)
+    nbytes = L.i2l_linear_bwd_workspace_bytes(B, K, E)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(L.i2l_linear_bias_act_bwd(feat.data_ptr(), lin.weight.detach().data_ptr(), state["out"].data_ptr(),
+                                         denc.data_ptr(), dfeat.data_ptr(), grads["embedding_layer.weight"].data_ptr(),
+                                         grads["embedding_layer.bias"].data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
+                                         _lib.stream_ptr()), "linear_bias_act_bwd")
+    dy = dfeat
+    for i in reversed(range(len(enc.conv_filters))):
+        conv = enc.cnn_layers[3 * i]
+        xin = state["x"] if i == 0 else blocks[i - 1]
+        _, cin, h, w = xin.shape
+        dx = torch.empty_like(xin) if i > 0 else None          # images need no gradient
+        nbytes = L.i2l_conv_bwd_workspace_bytes(B, cin, h, w, conv.out_channels)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.i2l_conv3x3_relu_pool2_bwd(
+            xin.data_ptr(), conv.weight.detach().data_ptr(), blocks[i].data_ptr(), amax[i].data_ptr(),
+            dy.data_ptr(), _lib.ptr(dx), grads[f"cnn_layers.{3 * i}.weight"].data_ptr(),
+            grads[f"cnn_layers.{3 * i}.bias"].data_ptr(), B, cin, h, w, conv.out_channels, ws.data_ptr(), nbytes,
+            _lib.stream_ptr()), "conv3x3_relu_pool2_bwd")
+        dy = dx

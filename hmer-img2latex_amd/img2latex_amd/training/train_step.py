@@ -1,0 +1,108 @@
+"""One optimisation step of the reference's Trainer, fp32 branch (trainer.py:303-343):
+
+    targets = formulas[:, 1:]                                        :306
+    outputs = model(images, formulas)                                :334
+    loss = CrossEntropyLoss(ignore_index=PAD, label_smoothing=0.1)   :111-115,335-336
+    loss.backward(); clip_grad_norm_(5.0); Adam(lr, weight_decay).step(); zero_grad   :337-343
+
+run entirely with the HIP kernels: training forward of encoder and decoder, fused CE, BPTT,
+conv/linear backward writing straight into ONE flat gradient buffer, one all-reduce of that
+buffer when data-parallel, then a fused clip + Adam over the flat parameter buffer.  No host
+synchronisation inside the step; ``loss`` / ``total_norm`` stay on the device until read.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib
+from ..model._train_fn import (decoder_train_backward, decoder_train_forward, encoder_train_backward,
+                               encoder_train_forward)
+from .dp import all_reduce_gradients, broadcast_parameters
+
+
+class TrainStep:
+    def __init__(self, model, lr: float = 1e-3, weight_decay: float = 1e-4, clip_grad_norm: float = 5.0,
+                 pad_token_id: int = 0, label_smoothing: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group=None, seed: int = 0):
+        self.model = model
+        self.lr, self.weight_decay, self.clip = lr, weight_decay, clip_grad_norm
+        self.pad, self.smoothing, self.betas, self.eps = pad_token_id, label_smoothing, betas, eps
+        self.group = process_group
+        self.step_count = 0
+        self.seed = seed
+        params = [p for p in model.parameters()]
+        if not params or not params[0].is_cuda:
+            raise RuntimeError("img2latex_amd: TrainStep needs the model on a ROCm device (no CPU fallback)")
+        dev = params[0].device
+        # 16-byte aligned slices of one flat buffer; parameters become views into it (state_dict unchanged)
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for name, p in model.named_parameters():
+            self.offsets[name] = off
+            off += (p.numel() + 3) // 4 * 4
+        self.n = off
+        self.flat_params = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(self.n + 4, dtype=torch.float32, device=dev)   # [n] loss sum, [n+1] count
+        self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.grad_views: Dict[str, torch.Tensor] = {}
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                o = self.offsets[name]
+                view = self.flat_params[o:o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+                self.grad_views[name] = self.flat_grads[o:o + p.numel()].view_as(p)
+        broadcast_parameters(self.flat_params, 0, self.group)
+        L = _lib.lib()
+        self._opt_ws = torch.empty(L.i2l_optimizer_workspace_bytes(), dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------
+    def forward_backward(self, images: torch.Tensor, formulas: torch.Tensor) -> torch.Tensor:
+        """Training forward + backward for this rank's shard; fills flat_grads (gradient of the SUM of the
+        per-token losses), flat_grads[n] = loss sum, flat_grads[n+1] = non-PAD count.  Returns logits."""
+        model = self.model
+        L = _lib.lib()
+        formulas = formulas.to(torch.int32) if formulas.dtype != torch.int32 else formulas
+        tokens_in = formulas[:, :-1].contiguous()                    # seq2seq.py:115-120
+        targets = formulas[:, 1:].contiguous()                       # trainer.py:306
+        B, T = tokens_in.shape
+        self.step_seed = (self.seed * 1000003 + self.step_count) & 0x3FFFFFFFFFFFFFFF
+        enc, enc_state = encoder_train_forward(model.encoder, images)
+        logits, dec_state = decoder_train_forward(model.decoder, enc, tokens_in, self.step_seed)
+        V = logits.shape[-1]
+        dlogits = torch.empty_like(logits)
+        nbytes = L.i2l_ce_workspace_bytes(B * T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=logits.device)
+        _lib.check(L.i2l_ce_label_smooth_fwd_bwd(logits.data_ptr(), targets.data_ptr(), B * T, V, self.pad,
+                                                 self.smoothing, ws.data_ptr(), nbytes, dlogits.data_ptr(),
+                                                 self.flat_grads.data_ptr() + 4 * self.n, _lib.stream_ptr()),
+                   "ce_label_smooth_fwd_bwd")
+        dgr = {n[len("decoder."):]: g for n, g in self.grad_views.items() if n.startswith("decoder.")}
+        denc = decoder_train_backward(model.decoder, dec_state, dlogits, dgr)
+        egr = {n[len("encoder."):]: g for n, g in self.grad_views.items() if n.startswith("encoder.")}
+        encoder_train_backward(model.encoder, enc_state, denc, egr)
+        return logits
+
+    def apply(self) -> None:
+        """All-reduce (data parallel), then clip + Adam; bumps the step counter."""
+        L = _lib.lib()
+        all_reduce_gradients(self.flat_grads, self.group)
+        self.step_count += 1
+        _lib.check(L.i2l_grad_clip_adam_step(
+            self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
+            self.exp_avg_sq.data_ptr(), self.n, self.flat_grads.data_ptr() + 4 * (self.n + 1), float(self.clip),
+            float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+            self.step_count, self._opt_ws.data_ptr(), self._opt_ws.numel(), self.stats.data_ptr(),
+            _lib.stream_ptr()), "grad_clip_adam_step")
+
+    def step(self, images: torch.Tensor, formulas: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """trainer.py:303-343 for one batch.  Returns device tensors (no sync): loss, total_norm, count."""
+        self.model.train()
+        self.forward_backward(images, formulas)
+        self.apply()
+        count = self.flat_grads[self.n + 1]
+        return dict(loss=self.flat_grads[self.n] / count.clamp(min=1.0), total_norm=self.stats[0], count=count)

@@ -204,6 +204,17 @@ int i2l_ce_label_smooth_fwd_bwd(const float* logits, const int32_t* targets, int
                                 float label_smoothing, void* workspace, size_t workspace_bytes,
                                 float* dlogits_out, float* loss_sum_and_count_out, i2l_stream_t stream);
 
+/* clip_grad_norm_(max_norm) + Adam(lr, betas, eps, coupled L2 weight_decay) over flat fp32 buffers of
+ * n elements (trainer.py:91-93,338-342).  grads hold the gradient of the SUM loss; count_ptr (device,
+ * may be NULL = 1) is the number of non-pad target tokens the sum runs over (the GLOBAL count after the
+ * data-parallel all-reduce).  step >= 1 is the optimizer step number (bias correction).
+ * stats_out (device, 3 floats): total gradient norm, clip coefficient, 1/count.  max_norm <= 0: no clipping. */
+size_t i2l_optimizer_workspace_bytes(void);
+int i2l_grad_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                            const float* count_ptr, float max_norm, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, void* workspace, size_t workspace_bytes,
+                            float* stats_out, i2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

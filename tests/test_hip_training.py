@@ -131,3 +131,52 @@ def test_conv_bwd_odd_shapes():
         rel_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, "dx")
         rel_close(dw.cpu().numpy(), w.grad.numpy(), 2e-4, "dw")
         rel_close(db.cpu().numpy(), b.grad.numpy(), 2e-4, "db")
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_train_step_vs_reference_golden(name):
+    """trainer.py:303-343 for one batch against fixture G6 produced by the REAL reference:
+    loss, per-parameter gradient norms, total norm before clipping, parameters after one Adam step."""
+    from img2latex_amd.training import TrainStep
+    d, cfg, m = build(name)
+    big = name in ("primary", "secondary")
+    T = 24 if big else 12
+    forms = torch.from_numpy(synth.make_formulas(4, T, cfg["vocab_size"], seed=777, min_len=5)).to(DEV)
+    x = images(cfg, device=DEV)
+    names = json.loads(str(d["g6_param_names"]))
+    ts = TrainStep(m, lr=1e-3, weight_decay=1e-4, clip_grad_norm=5.0, pad_token_id=PAD, label_smoothing=0.1)
+    assert [n for n, _ in m.named_parameters()] == names
+    m.train()
+    logits = ts.forward_backward(x, forms)
+    if "g6_logits" in d:
+        rel_close(logits.cpu().numpy(), d["g6_logits"], 1e-4, "logits")
+    else:
+        rel_close(sample(logits), d["g6_logits_sample"], 1e-4, "logits")
+    count = float(ts.flat_grads[ts.n + 1])
+    loss = float(ts.flat_grads[ts.n]) / count
+    assert count == float((forms[:, 1:] != PAD).sum())
+    assert abs(loss - float(d["g6_loss"])) <= 1e-5 * max(1.0, abs(float(d["g6_loss"])))
+    # same arithmetic as the fixture (torch CPU fp32 .norm(): its rounding drifts by 6e-4 on the 21M-element FC weight)
+    gn = np.array([float((ts.grad_views[n].cpu() / count).norm()) for n in names])
+    np.testing.assert_allclose(gn, d["g6_grad_norms"], rtol=3e-4, atol=1e-7)
+    ts.apply()
+    assert abs(float(ts.stats[0]) - float(d["g6_total_norm"])) <= 3e-4 * float(d["g6_total_norm"])
+    sdict = dict(m.named_parameters())
+    after = np.stack([sample(sdict[k], 8)[:8] if sdict[k].numel() >= 8 else np.resize(sdict[k].detach().cpu().numpy().ravel(), 8)
+                      for k in names])
+    np.testing.assert_allclose(after, d["g6_param_sample_after"], rtol=0, atol=3e-6)
+    # the parameters are views into the flat buffer and the state_dict keys are untouched
+    assert list(m.state_dict().keys()) == names
+
+
+def test_train_step_loss_decreases_and_dropout_runs():
+    from img2latex_amd.training import TrainStep
+    cfg = synth.model_config(vocab_size=50, embedding_dim=32, hidden_dim=64, lstm_layers=2, attention=True, channels=1,
+                             img_height=16, img_width=32, conv_filters=(4, 8, 16), dropout=0.3)
+    torch.manual_seed(0)
+    m = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg)).to(DEV)
+    ts = TrainStep(m, lr=3e-3, seed=11)
+    x = images(cfg, batch=8, device=DEV)
+    forms = torch.from_numpy(synth.make_formulas(8, 14, cfg["vocab_size"], seed=5, min_len=6)).to(DEV)
+    losses = [float(ts.step(x, forms)["loss"]) for _ in range(30)]
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses[::5]
