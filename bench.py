@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--seq", type=int, default=150, help="decode steps (max_length)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["greedy", "beam", "train"], default="greedy",
+                    help="greedy = the headline (BASELINE configs[1]); beam = configs[2] (128 images x k=5, attention); "
+                         "train = configs[3] (teacher-forced fwd+bwd+CE+clip+Adam, 64 samples/GPU, RCCL all-reduce)")
     ap.add_argument("--overlap", action="store_true",
                     help="two streams: encoder of batch i+1 overlaps decode of batch i (default: one stream, "
                          "batches back to back, so the per-kernel event times are undisturbed)")
@@ -82,6 +85,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.mode != "greedy":
+        return extra_modes(args, world, rank, dev, dist)
     B, T = args.batch, args.seq
     cfg = synth.model_config()                                        # primary dims: E=Hd=256, L=1, V=512, 3x64x320
     sd_kw = dict(seed=42, out_scale=8.0, enc_scale=16.0)              # = tests/golden/primary_cfg2 weights
@@ -205,6 +210,70 @@ def main():
         result["cpu_baseline"] = cpu_baseline(cfg, sd_kw, B, T)
     if rank == 0:
         print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def extra_modes(args, world, rank, dev, dist):
+    """Secondary configs of BASELINE.json (not the driver's headline line)."""
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.mode == "beam":
+        n, k, T = 128, 5, args.seq
+        cfg = synth.model_config(attention=True)
+        sd_kw = dict(seed=42, out_scale=12.0, enc_scale=16.0, end_clock=(0.05, 12.0, 6.0))
+        model = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+        model.load_state_dict({k_: torch.from_numpy(v) for k_, v in synth.make_state_dict(cfg, **sd_kw).items()})
+        model = model.to(dev).eval()
+        images = torch.from_numpy(synth.make_images(n, cfg, seed=1234 + rank)).to(dev)
+        out = [None]
+
+        def one_step():
+            with torch.no_grad():
+                out[0] = model.beam_search_batch(model.encoder(images), synth.START, synth.END, T, k)
+        unit = lambda: float(sum(len(s) for s in out[0]))
+        name, conf = "beam-search decoded tokens/sec (best sequences)", {"workload": "cnn_lstm+attention beam k=5 (BASELINE configs[2])", "images_per_gpu": n, "beam": k, "max_length": T}
+    else:
+        Bt, T = 64, 150
+        cfg = synth.model_config(dropout=0.1)
+        model = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+        model.load_state_dict({k_: torch.from_numpy(v) for k_, v in synth.make_state_dict(cfg, seed=42).items()})
+        model = model.to(dev).train()
+        from img2latex_amd.training import TrainStep
+        ts = TrainStep(model, seed=1)
+        images = torch.from_numpy(synth.make_images(Bt, cfg, seed=1234 + rank)).to(dev)
+        forms = torch.from_numpy(synth.make_formulas(Bt, T, cfg["vocab_size"], seed=777 + rank)).to(torch.int32).to(dev)
+
+        def one_step():
+            ts.step(images, forms)
+        unit = lambda: float(Bt * (T - 1))
+        name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "parallelism": f"dp{world}: one flat-buffer all-reduce"}
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    units = unit()
+    if dist is not None:
+        tmax = torch.tensor([elapsed, 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0].item())
+        tot = torch.tensor([units], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        units = float(tot.item())
+    if rank == 0:
+        print(json.dumps({"metric": name, "value": round(units * args.steps / elapsed, 1), "unit": "tokens/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": conf}))
     if dist is not None:
         dist.destroy_process_group()
 

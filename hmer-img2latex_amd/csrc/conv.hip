@@ -403,28 +403,34 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__
     }
 }
 
-// db[c] = sum_{b,pos} dyp[b][c][pos]: one workgroup per channel, fixed order.
-__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ dyp, float* __restrict__ db, int B,
-                                                        int C, size_t HW) {
+// db[c] = sum_{b,pos} dyp[b][c][pos]: grid (C, B) partial sums per image, then an ordered sum over images
+// (deterministic).
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ dyp, double* __restrict__ partial,
+                                                        int B, int C, size_t HW) {
     __shared__ double red[256];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* p = dyp + ((size_t)b * C + c) * HW;
     double s = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const float* p = dyp + ((size_t)b * C + c) * HW;
-        for (size_t i = threadIdx.x; i < HW; i += 256) s += p[i];
-    }
+    for (size_t i = threadIdx.x; i < HW; i += 256) s += p[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) db[c] = (float)red[0];
+    if (threadIdx.x == 0) partial[(size_t)c * B + b] = red[0];
+}
+__global__ void plane_sum_final_kernel(const double* __restrict__ partial, float* __restrict__ db, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += partial[(size_t)c * B + b];
+    db[c] = (float)s;
 }
 
 constexpr int WG_CHUNK = 32;    // images per weight-gradient GEMM call
 
-struct BwdLayout { size_t dyp, colT, gemm, wpack, total; size_t gemm_bytes, wpack_bytes; int chunk; };
+struct BwdLayout { size_t dyp, colT, gemm, wpack, psum, total; size_t gemm_bytes, wpack_bytes; int chunk; };
 
 BwdLayout bwd_layout(int B, int Cin, int H, int W, int Cout) {
     BwdLayout o{};
@@ -437,6 +443,7 @@ BwdLayout bwd_layout(int B, int Cin, int H, int W, int Cout) {
     o.gemm = off; off += i2l_align(o.gemm_bytes);
     o.wpack_bytes = i2l_conv_workspace_bytes(Cout, Cin);         // data-gradient conv: Cout -> Cin channels
     o.wpack = off; off += i2l_align(o.wpack_bytes);
+    o.psum = off; off += i2l_align((size_t)B * Cout * sizeof(double));
     o.total = off;
     return o;
 }
@@ -470,7 +477,11 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
                            (size_t)B * Cout, H, W, Hp, Wp);
         I2L_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(plane_sum_kernel, dim3(Cout), dim3(256), 0, s, (const float*)dyp, db, B, Cout, HW);
+    if (B > 65535) return I2L_ERR_UNSUPPORTED;
+    double* psum = reinterpret_cast<double*>(base + lo.psum);
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(Cout, B), dim3(256), 0, s, (const float*)dyp, psum, B, Cout, HW);
+    I2L_CHECK_LAUNCH();
+    hipLaunchKernelGGL(plane_sum_final_kernel, dim3(i2l_cdiv(Cout, 64)), dim3(64), 0, s, (const double*)psum, db, B, Cout);
     I2L_CHECK_LAUNCH();
     // weight gradient: dw[co][(ci,tap)] = sum_b sum_pos dyp[b][co][pos] * colT[b][(ci,tap)][pos]
     for (int b0 = 0; b0 < B; b0 += lo.chunk) {

@@ -1,0 +1,96 @@
+"""Data-parallel host logic on CPU: world_size 2, gloo.  Each rank computes the gradient of the SUM
+loss of its shard (with the CPU oracle, the only CPU arithmetic available to tests), the product's
+dp helpers all-reduce one flat buffer [grads..., loss_sum, count] and divide by the GLOBAL count;
+the result must equal the single-process full-batch gradient of the reference's mean loss."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import img2latex_oracle as O
+from helpers import PAD
+from img2latex_amd import synth
+from img2latex_amd.training.dp import all_reduce_gradients, broadcast_parameters, shard_batch
+
+CFG = dict(vocab_size=50, embedding_dim=32, hidden_dim=64, lstm_layers=1, attention=False, channels=1,
+           img_height=16, img_width=32, conv_filters=(4, 8, 16))
+B, T = 7, 10                      # 7 rows over 2 ranks: ragged shards (4 + 3)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _sum_loss_grads(sd, cfg, x, forms):
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    logits = O.seq2seq_forward(params, cfg, x, forms)
+    logp = torch.log_softmax(logits, dim=-1)
+    tgt = forms[:, 1:]
+    keep = tgt != PAD
+    per = 0.9 * -logp.gather(-1, tgt.unsqueeze(-1)).squeeze(-1) + 0.1 * -logp.mean(-1)
+    loss_sum = (per * keep).sum()
+    loss_sum.backward()
+    flat = torch.cat([params[k].grad.reshape(-1) for k in sd] + [loss_sum.detach().reshape(1), keep.sum().float().reshape(1)])
+    return flat
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = synth.model_config(**CFG)
+    sd = O.to_torch_sd(synth.make_state_dict(cfg, seed=3 + rank))          # ranks start DIFFERENT on purpose
+    flat_p = torch.cat([v.reshape(-1) for v in sd.values()])
+    broadcast_parameters(flat_p, src=0)                                     # ... and are made identical
+    off = 0
+    for k in sd:
+        n = sd[k].numel()
+        sd[k] = flat_p[off:off + n].view_as(sd[k]).clone()
+        off += n
+    x = torch.from_numpy(synth.make_images(B, cfg, seed=1234))
+    forms = torch.from_numpy(synth.make_formulas(B, T, cfg["vocab_size"], seed=777, min_len=4))
+    lo, hi = shard_batch(B, rank, world)
+    flat = _sum_loss_grads(sd, cfg, x[lo:hi], forms[lo:hi])
+    all_reduce_gradients(flat)
+    grads = flat[:-2] / flat[-1]
+    if rank == 0:
+        full = _sum_loss_grads(sd, cfg, x, forms)
+        want = full[:-2] / full[-1]
+        out["max_err"] = float((grads - want).abs().max())
+        out["scale"] = float(want.abs().max())
+        out["count"] = (float(flat[-1]), float(full[-1]))
+        out["loss"] = (float(flat[-2] / flat[-1]), float(full[-2] / full[-1]))
+    gathered = [torch.zeros_like(grads) for _ in range(world)]
+    dist.all_gather(gathered, grads)
+    if rank == 0:
+        out["identical_across_ranks"] = bool(torch.equal(gathered[0], gathered[1]))
+    dist.destroy_process_group()
+
+
+def test_shard_batch_covers_everything():
+    for n in (1, 7, 64, 512):
+        for world in (1, 2, 3, 8):
+            spans = [shard_batch(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_allreduce_equals_full_batch():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out["count"][0] == out["count"][1]
+    assert abs(out["loss"][0] - out["loss"][1]) < 1e-6
+    assert out["max_err"] <= 1e-6 * max(1.0, out["scale"]), dict(out)
+    assert out["identical_across_ranks"]

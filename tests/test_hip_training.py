@@ -180,3 +180,34 @@ def test_train_step_loss_decreases_and_dropout_runs():
     forms = torch.from_numpy(synth.make_formulas(8, 14, cfg["vocab_size"], seed=5, min_len=6)).to(DEV)
     losses = [float(ts.step(x, forms)["loss"]) for _ in range(30)]
     assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses[::5]
+
+
+def test_data_parallel_shards_equal_full_batch():
+    """SURVEY 8e parity for the DP step, emulated in one process: two ranks' flat buffers are summed
+    (what the RCCL all-reduce does), then every rank applies clip + Adam with the GLOBAL count; the
+    parameters must equal the single-process full-batch step."""
+    from img2latex_amd.training import TrainStep, shard_batch
+    name = "tiny_l2_attn"
+    _, cfg, m_full = build(name)
+    _, _, m_a = build(name)
+    _, _, m_b = build(name)
+    B, T = 9, 13
+    x = images(cfg, batch=B, seed=31, device=DEV)
+    forms = torch.from_numpy(synth.make_formulas(B, T, cfg["vocab_size"], seed=32, min_len=4)).to(DEV)
+    full, ra, rb = TrainStep(m_full), TrainStep(m_a), TrainStep(m_b)
+    full.step(x, forms)
+    (lo0, hi0), (lo1, hi1) = shard_batch(B, 0, 2), shard_batch(B, 1, 2)
+    for m_ in (m_a, m_b):
+        m_.train()
+    ra.forward_backward(x[lo0:hi0].contiguous(), forms[lo0:hi0].contiguous())
+    rb.forward_backward(x[lo1:hi1].contiguous(), forms[lo1:hi1].contiguous())
+    total = ra.flat_grads + rb.flat_grads                      # == all_reduce(SUM)
+    ra.flat_grads.copy_(total)
+    rb.flat_grads.copy_(total)
+    ra.apply()
+    rb.apply()
+    assert torch.equal(ra.flat_params, rb.flat_params)         # replicas stay bit-identical
+    assert float(ra.flat_grads[ra.n + 1]) == float(full.flat_grads[full.n + 1])
+    err = float((ra.flat_params - full.flat_params).abs().max())
+    assert err <= 1e-5, err                                    # SURVEY 8e: within 1e-5 after one step
+    assert abs(float(ra.stats[0]) - float(full.stats[0])) <= 1e-4 * float(full.stats[0])
