@@ -64,9 +64,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--seq", type=int, default=150, help="decode steps (max_length)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["greedy", "beam", "train"], default="greedy",
+    ap.add_argument("--mode", choices=["greedy", "beam", "train", "resnet"], default="greedy",
                     help="greedy = the headline (BASELINE configs[1]); beam = configs[2] (128 images x k=5, attention); "
-                         "train = configs[3] (teacher-forced fwd+bwd+CE+clip+Adam, 64 samples/GPU, RCCL all-reduce)")
+                         "train = configs[3] (teacher-forced fwd+bwd+CE+clip+Adam, 64 samples/GPU, RCCL all-reduce); "
+                         "resnet = configs[4] (ResNet50 encoder in bf16 + greedy decode, batch 256)")
     ap.add_argument("--overlap", action="store_true",
                     help="two streams: encoder of batch i+1 overlaps decode of batch i (default: one stream, "
                          "batches back to back, so the per-kernel event times are undisturbed)")
@@ -237,6 +238,38 @@ def extra_modes(args, world, rank, dev, dist):
                 out[0] = model.beam_search_batch(model.encoder(images), synth.START, synth.END, T, k)
         unit = lambda: float(sum(len(s) for s in out[0]))
         name, conf = "beam-search decoded tokens/sec (best sequences)", {"workload": "cnn_lstm+attention beam k=5 (BASELINE configs[2])", "images_per_gpu": n, "beam": k, "max_length": T}
+    elif args.mode == "resnet":
+        Bn, T = args.batch, args.seq
+        cfg = synth.model_config()
+        enc_p = dict(img_height=64, img_width=320, channels=3, model_name="resnet50", embedding_dim=256,
+                     freeze_backbone=True)
+        model = Seq2SeqModel("resnet_lstm", cfg["vocab_size"], enc_p, synth.decoder_params(cfg))
+        shapes = [(k_, tuple(v.shape)) for k_, v in model.encoder.state_dict().items()]
+        esd = synth.make_resnet_state_dict(shapes, seed=5)
+        dsd = {k_: v for k_, v in synth.make_state_dict(cfg, seed=42, out_scale=8.0).items() if k_.startswith("decoder.")}
+        full = {"encoder." + k_: torch.from_numpy(v) for k_, v in esd.items()}
+        full.update({k_: torch.from_numpy(v) for k_, v in dsd.items()})
+        model.load_state_dict(full)
+        model = model.to(dev).eval()
+        images = torch.from_numpy(synth.make_images(Bn, cfg, seed=1234 + rank)).to(dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        enc_ms = []
+
+        def one_step():
+            with torch.no_grad():
+                ev[0].record()
+                enc = model.encoder(images)
+                ev[1].record()
+                ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
+                ids.cpu()
+                enc_ms.append(ev[0].elapsed_time(ev[1]))
+        unit = lambda: float(Bn * T)
+        # ResNet-50 trunk at 64x320: 4.09 GMAC x (64*320)/(224*224)
+        gflop = 2 * 4.09 * (64 * 320) / (224 * 224) * Bn
+        name = "decoded LaTeX tokens/sec, ResNet50 bf16 encoder + LSTM greedy decode"
+        conf = {"workload": "resnet50_lstm greedy (BASELINE configs[4])", "batch_per_gpu": Bn, "image": "3x64x320",
+                "decode_steps": T, "encoder_dtype": "bf16 (fp32 accumulate)", "encoder_ms": enc_ms,
+                "encoder_gflop": round(gflop, 1)}
     else:
         Bt, T = 64, 150
         cfg = synth.model_config(dropout=0.1)
@@ -269,6 +302,12 @@ def extra_modes(args, world, rank, dev, dist):
         tot = torch.tensor([units], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         units = float(tot.item())
+    if args.mode == "resnet":
+        ms = float(np.median(conf["encoder_ms"][-args.steps:]))
+        conf["encoder_ms"] = round(ms, 4)
+        conf["encoder_images_per_s"] = round(args.batch / ms * 1e3, 1)
+        conf["encoder_tflops"] = round(conf["encoder_gflop"] / ms, 2)
+        conf["encoder_frac_of_bf16_dense_peak_2500TF"] = round(conf["encoder_gflop"] / ms / 2500.0, 4)
     if rank == 0:
         print(json.dumps({"metric": name, "value": round(units * args.steps / elapsed, 1), "unit": "tokens/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

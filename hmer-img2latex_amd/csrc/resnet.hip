@@ -1,0 +1,306 @@
+// bf16 building blocks of the ResNet encoder (reference encoder.py:132-249: torchvision ResNet trunk
+// minus fc, run at :242) for inference: activations live in HBM as NHWC bf16, every convolution is a
+// GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) with BatchNorm folded
+// into a per-channel scale/bias and the residual add + ReLU fused into the epilogue.
+//   1x1 stride-1 convs read the activation tensor directly ([B*H*W][Cin] is already the A matrix);
+//   3x3 / 7x7 / strided convs go through an im2col image [M][taps*Cin] (K contiguous).
+// Parity status: UNPINNED (torchvision is not installed and the reference fetches remote weights;
+// SURVEY.md 8c) -- tests compare against this repo's own fp32 restatement of the v1.5 architecture.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);          // round to nearest even (finite inputs)
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+
+// ------------------------------------------------------------------ bf16 GEMM with fused epilogue
+// out[m][n] = act( acc[m][n] * scale[n] + bias[n] + res[m][n] ),  acc = sum_k A[m][k] * W[n][k]
+constexpr int GM = 128, GN = 128, GK = 32, GLD = 40;      // LDS row stride 40 bf16 = 80 B: conflict-free b128 reads
+
+struct BfGemm {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    const float* scale; const float* bias;
+    const bf16_t* res; long ldr;
+    bf16_t* C; long ldc;
+    int M, N, K, relu;
+};
+
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(BfGemm g) {
+    __shared__ __attribute__((aligned(16))) bf16_t As[GM * GLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ws[GN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * GN, m0 = blockIdx.y * GM;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int k0 = 0; k0 < g.K; k0 += GK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;                 // 128 rows x 4 chunks of 8 bf16
+            const int row = idx >> 2, c8 = (idx & 3) * 8;
+            uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
+            if (k0 + c8 < g.K) {                           // K % 8 == 0
+                if (m0 + row < g.M) va = *reinterpret_cast<const uint4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + c8);
+                if (n0 + row < g.N) vw = *reinterpret_cast<const uint4*>(g.W + (size_t)(n0 + row) * g.ldw + k0 + c8);
+            }
+            *reinterpret_cast<uint4*>(&As[row * GLD + c8]) = va;
+            *reinterpret_cast<uint4*>(&Ws[row * GLD + c8]) = vw;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GK; ks += 16) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + t * 32 + li) * GLD + ks + 8 * lh]);
+                b[t] = *reinterpret_cast<const bf16x8*>(&Ws[(wn * 64 + t * 32 + li) * GLD + ks + 8 * lh]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 64 + nt * 32 + li;
+        if (n >= g.N) continue;
+        const float sc = g.scale ? g.scale[n] : 1.f, bi = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= g.M) continue;
+                float v = acc[mt][nt][r] * sc + bi;
+                if (g.res) v += bf2f(g.res[(size_t)m * g.ldr + n]);
+                if (g.relu) v = fmaxf(v, 0.f);
+                g.C[(size_t)m * g.ldc + n] = f2bf(v);
+            }
+    }
+}
+
+// ------------------------------------------------------------------ layout / packing kernels
+// wp[co][(tap*Cin + ci)] (K padded to Kp with zeros) = w[co][ci][tap]; scale/bias = folded BatchNorm
+__global__ __launch_bounds__(256) void pack_conv_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp,
+                                                             int Cout, int Cin, int taps, int Kp) {
+    const size_t total = (size_t)Cout * Kp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i / Kp), k = (int)(i - (size_t)co * Kp);
+        float v = 0.f;
+        if (k < taps * Cin) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            v = w[((size_t)co * Cin + ci) * taps + tap];
+        }
+        wp[i] = f2bf(v);
+    }
+}
+__global__ void fold_bn_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                               float* __restrict__ scale, float* __restrict__ bias, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(var[c] + eps);
+    scale[c] = s;
+    bias[c] = beta[c] - mean[c] * s;
+}
+
+// im2col from NCHW fp32 (the images): col[m][(tap*Cin+ci)] bf16, K padded to Kp
+__global__ __launch_bounds__(256) void im2col_nchw_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int B,
+                                                              int Cin, int H, int W, int Ho, int Wo, int kh, int kw,
+                                                              int stride, int pad, int Kp) {
+    const size_t total = (size_t)B * Ho * Wo * Kp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / Kp;
+        const int k = (int)(i - m * Kp);
+        float v = 0.f;
+        if (k < kh * kw * Cin) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int ky = tap / kw, kx = tap - ky * kw;
+            const int xo = (int)(m % Wo);
+            const size_t t = m / Wo;
+            const int yo = (int)(t % Ho), b = (int)(t / Ho);
+            const int yi = yo * stride - pad + ky, xi = xo * stride - pad + kx;
+            if (yi >= 0 && yi < H && xi >= 0 && xi < W) v = x[(((size_t)b * Cin + ci) * H + yi) * W + xi];
+        }
+        col[i] = f2bf(v);
+    }
+}
+
+// im2col from NHWC bf16, 8 channels (16 bytes) per thread; Cin % 8 == 0
+__global__ __launch_bounds__(256) void im2col_nhwc_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col,
+                                                               int B, int Cin, int H, int W, int Ho, int Wo, int kh,
+                                                               int kw, int stride, int pad) {
+    const int c8n = Cin / 8;
+    const size_t total = (size_t)B * Ho * Wo * kh * kw * c8n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        size_t t = i / c8n;
+        const int tap = (int)(t % (kh * kw));
+        const size_t m = t / (kh * kw);
+        const int ky = tap / kw, kx = tap - ky * kw;
+        const int xo = (int)(m % Wo);
+        const size_t t2 = m / Wo;
+        const int yo = (int)(t2 % Ho), b = (int)(t2 / Ho);
+        const int yi = yo * stride - pad + ky, xi = xo * stride - pad + kx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (yi >= 0 && yi < H && xi >= 0 && xi < W)
+            v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + yi) * W + xi) * Cin + c8 * 8);
+        *reinterpret_cast<uint4*>(col + (m * kh * kw + tap) * Cin + c8 * 8) = v;
+    }
+}
+
+// MaxPool2d(3, stride 2, padding 1) on NHWC bf16, 8 channels per thread
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                                int B, int C, int H, int W, int Ho, int Wo) {
+    const int c8n = C / 8;
+    const size_t total = (size_t)B * Ho * Wo * c8n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        size_t t = i / c8n;
+        const int xo = (int)(t % Wo); t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yi = 2 * yo - 1 + ky, xi = 2 * xo - 1 + kx;
+                if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + yi) * W + xi) * C + c8 * 8);
+                const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], bf2f(h[e]));
+            }
+        bf16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(best[e]);
+        *reinterpret_cast<uint4*>(y + (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8) = *reinterpret_cast<const uint4*>(o);
+    }
+}
+
+// AdaptiveAvgPool2d(1) + Flatten: (B,H,W,C) bf16 -> (B,C) fp32
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int B,
+                                                           int C, int HW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += bf2f(x[((size_t)b * HW + p) * C + c]);
+    y[i] = s / (float)HW;
+}
+
+int grid_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                                int pad) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return 0;
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    const int Kp = i2l_cdiv(kh * kw * Cin, 8) * 8;
+    size_t bytes = i2l_align((size_t)Cout * Kp * sizeof(bf16_t)) + 2 * i2l_align((size_t)Cout * sizeof(float));
+    const bool direct = kh == 1 && kw == 1 && stride == 1 && pad == 0 && Cin % 8 == 0;
+    if (!direct) bytes += i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
+    return bytes;
+}
+
+// y = act( BN(conv(x, w)) + residual ), NHWC bf16 in/out (x may instead be the NCHW fp32 image batch).
+extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const float* w, const float* bn_weight,
+                                         const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps,
+                                         const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int kh,
+                                         int kw, int stride, int pad, int relu, void* workspace, size_t workspace_bytes,
+                                         i2l_stream_t stream) {
+    if (!x || !w || !y || !bn_weight || !bn_bias || !bn_mean || !bn_var) return I2L_ERR_ARG;
+    const size_t need = i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad);
+    if (need == 0) return I2L_ERR_ARG;
+    if (!workspace || workspace_bytes < need) return I2L_ERR_WORKSPACE;
+    if (!x_is_nchw_f32 && Cin % 8 != 0) return I2L_ERR_UNSUPPORTED;
+    if (Cout % 8 != 0) return I2L_ERR_UNSUPPORTED;
+    hipStream_t s = i2l_s(stream);
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    const int taps = kh * kw, Kp = i2l_cdiv(taps * Cin, 8) * 8;
+    char* base = static_cast<char*>(workspace);
+    bf16_t* wp = reinterpret_cast<bf16_t*>(base);
+    size_t off = i2l_align((size_t)Cout * Kp * sizeof(bf16_t));
+    float* scale = reinterpret_cast<float*>(base + off); off += i2l_align((size_t)Cout * sizeof(float));
+    float* bias = reinterpret_cast<float*>(base + off); off += i2l_align((size_t)Cout * sizeof(float));
+    bf16_t* col = reinterpret_cast<bf16_t*>(base + off);
+
+    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(grid_for((size_t)Cout * Kp)), dim3(256), 0, s, w, wp, Cout, Cin, taps, Kp);
+    I2L_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_bn_kernel, dim3(i2l_cdiv(Cout, 256)), dim3(256), 0, s, bn_weight, bn_bias, bn_mean, bn_var,
+                       bn_eps, scale, bias, Cout);
+    I2L_CHECK_LAUNCH();
+    const size_t M = (size_t)B * Ho * Wo;
+    if (M > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
+    BfGemm g{};
+    const bool direct = !x_is_nchw_f32 && kh == 1 && kw == 1 && stride == 1 && pad == 0;
+    if (direct) {
+        g.A = static_cast<const bf16_t*>(x); g.lda = Cin;
+    } else {
+        if (x_is_nchw_f32)
+            hipLaunchKernelGGL(im2col_nchw_f32_kernel, dim3(grid_for(M * Kp)), dim3(256), 0, s,
+                               static_cast<const float*>(x), col, B, Cin, H, W, Ho, Wo, kh, kw, stride, pad, Kp);
+        else
+            hipLaunchKernelGGL(im2col_nhwc_bf16_kernel, dim3(grid_for(M * taps * (Cin / 8))), dim3(256), 0, s,
+                               static_cast<const bf16_t*>(x), col, B, Cin, H, W, Ho, Wo, kh, kw, stride, pad);
+        I2L_CHECK_LAUNCH();
+        g.A = col; g.lda = Kp;
+    }
+    g.W = wp; g.ldw = Kp;
+    g.scale = scale; g.bias = bias;
+    g.res = static_cast<const bf16_t*>(residual); g.ldr = Cout;
+    g.C = static_cast<bf16_t*>(y); g.ldc = Cout;
+    g.M = (int)M; g.N = Cout; g.K = Kp; g.relu = relu;
+    dim3 grid(i2l_cdiv(Cout, GN), i2l_cdiv((int)M, GM));
+    if (grid.y > 65535) return I2L_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, s, g);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+extern "C" int i2l_maxpool3x3s2_bf16_fwd(const void* x, void* y, int B, int H, int W, int C, i2l_stream_t stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return I2L_ERR_ARG;
+    if (C % 8 != 0) return I2L_ERR_UNSUPPORTED;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, i2l_s(stream),
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y), B, C, H, W, Ho, Wo);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+extern "C" int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H, int W, int C, i2l_stream_t stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return I2L_ERR_ARG;
+    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(i2l_cdiv(B * C, 256)), dim3(256), 0, i2l_s(stream),
+                       static_cast<const bf16_t*>(x), y, B, C, H * W);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}

@@ -205,3 +205,29 @@ def checksum(a: np.ndarray) -> float:
     f = np.asarray(a, dtype=np.float64).ravel()
     w = (np.arange(f.size, dtype=np.float64) % 251.0) + 1.0
     return float(np.dot(f, w))
+
+
+def make_resnet_state_dict(names_and_shapes, seed: int = 42) -> Dict[str, np.ndarray]:
+    """Deterministic ResNet weights for a given list of (state_dict key, shape): conv ~N(0, 2/fan_out)
+    (torchvision's init), BatchNorm with NON-trivial statistics (so that BN folding is exercised),
+    Linear U(+-1/sqrt(fan_in))."""
+    sd: Dict[str, np.ndarray] = {}
+    for name, shape in names_and_shapes:
+        shape = tuple(shape)
+        if name.endswith("num_batches_tracked"):
+            sd[name] = np.zeros(shape, dtype=np.int64)
+        elif name.endswith("running_var"):
+            sd[name] = uniform(seed, name, shape, 0.5, 1.5)
+        elif name.endswith("running_mean"):
+            sd[name] = uniform(seed, name, shape, -0.2, 0.2)
+        elif len(shape) == 4:
+            fan_out = shape[0] * shape[2] * shape[3]
+            sd[name] = (normal_like(seed, name, shape) * np.float32(math.sqrt(2.0 / fan_out))).astype(np.float32)
+        elif len(shape) == 2:
+            b = 1.0 / math.sqrt(shape[1])
+            sd[name] = uniform(seed, name, shape, -b, b)
+        elif name.endswith(".weight"):                       # BatchNorm gamma
+            sd[name] = uniform(seed, name, shape, 0.5, 1.5)
+        else:                                                # biases (BatchNorm beta, Linear bias)
+            sd[name] = uniform(seed, name, shape, -0.2, 0.2)
+    return sd

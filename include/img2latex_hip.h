@@ -78,6 +78,22 @@ int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, cons
                             float* dw, float* db, int M, int K, int N, int relu, void* workspace,
                             size_t workspace_bytes, i2l_stream_t stream);
 
+/* ResNet encoder building blocks (reference encoder.py:132-249: torchvision ResNet trunk at :242),
+ * inference, bf16 on the matrix cores with fp32 accumulation.  Activations are NHWC bf16 (void*).
+ *   y = act( BatchNorm_eval(conv(x, w)) + residual )    w (Cout,Cin,kh,kw) fp32, bn_* (Cout) fp32
+ * x is NHWC bf16 (B,H,W,Cin), or the NCHW fp32 image batch when x_is_nchw_f32 != 0 (the stem);
+ * residual is NHWC bf16 (B,Ho,Wo,Cout) or NULL; y NHWC bf16 (B,Ho,Wo,Cout). */
+size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const float* w, const float* bn_weight,
+                             const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps,
+                             const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int kh,
+                             int kw, int stride, int pad, int relu, void* workspace, size_t workspace_bytes,
+                             i2l_stream_t stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) on NHWC bf16: (B,H,W,C) -> (B,(H-1)/2+1,(W-1)/2+1,C). */
+int i2l_maxpool3x3s2_bf16_fwd(const void* x, void* y, int B, int H, int W, int C, i2l_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1) + Flatten: NHWC bf16 (B,H,W,C) -> fp32 (B,C). */
+int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H, int W, int C, i2l_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Decoder (reference img2latex/model/decoder.py, seq2seq.py, predictor.py)
  * ---------------------------------------------------------------------- */

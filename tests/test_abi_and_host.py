@@ -87,3 +87,28 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "img2latex_oracle" not in src and "import oracle" not in src, f
+
+
+def test_resnet_encoder_surface():
+    """state_dict keys follow the reference's nn.Sequential(*list(backbone.children())[:-1]) slicing
+    (encoder.py:198-199): conv1 -> resnet.0, bn1 -> resnet.1, layer1..4 -> resnet.4..7."""
+    from img2latex_amd.model import ResNetEncoder
+    enc = ResNetEncoder(model_name="resnet50", embedding_dim=128)
+    assert (enc.img_height, enc.img_width, enc.channels) == (64, 800, 3)               # encoder.py:163-170
+    keys = set(enc.state_dict().keys())
+    for k in ("resnet.0.weight", "resnet.1.running_mean", "resnet.1.num_batches_tracked", "resnet.4.0.conv1.weight",
+              "resnet.4.0.downsample.0.weight", "resnet.4.0.downsample.1.bias", "resnet.4.2.bn3.weight",
+              "resnet.5.0.conv2.weight", "resnet.6.5.conv3.weight", "resnet.7.2.bn3.running_var",
+              "embedding_layer.weight", "embedding_layer.bias"):
+        assert k in keys, k
+    assert enc.state_dict()["resnet.5.0.conv2.weight"].shape == (128, 128, 3, 3)
+    assert enc.state_dict()["resnet.5.0.downsample.0.weight"].shape == (512, 256, 1, 1)
+    assert enc.embedding_layer.in_features == 2048
+    assert sum(p.numel() for n, p in enc.named_parameters() if n.startswith("resnet.")) == 23508032   # resnet50 minus fc
+    # freeze_backbone=True: everything frozen except layer4 (encoder.py:201-210)
+    assert not enc.resnet[4][0].conv1.weight.requires_grad and enc.resnet[7][0].conv1.weight.requires_grad
+    assert ResNetEncoder(model_name="resnet18").embedding_layer.in_features == 512
+    with pytest.raises(ValueError):
+        ResNetEncoder(model_name="resnet42")
+    m = Seq2SeqModel("resnet_lstm", 50, {"model_name": "resnet18", "embedding_dim": 32}, {"hidden_dim": 64})
+    assert m.model_type == "resnet_lstm" and any(k.startswith("encoder.resnet.7.") for k in m.state_dict())

@@ -299,3 +299,29 @@ def test_greedy_pipeline_matches_serial():
         for b in batches[:3]:
             pipe.submit(b)
     pipe.drain()
+
+
+@pytest.mark.parametrize("model_name,hw", [("resnet18", (32, 64)), ("resnet50", (64, 96))])
+def test_resnet_encoder_vs_oracle(model_name, hw):
+    """bf16 MFMA trunk against the fp32 restatement (parity unpinned: no reference output exists)."""
+    import resnet_oracle as RO
+    from img2latex_amd.model import ResNetEncoder
+    enc = ResNetEncoder(hw[0], hw[1], 3, model_name=model_name, embedding_dim=64)
+    shapes = [(k, tuple(v.shape)) for k, v in enc.state_dict().items()]
+    np_sd = synth.make_resnet_state_dict(shapes, seed=5)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in np_sd.items()}, strict=True)
+    enc = enc.to(DEV).eval()
+    x = torch.from_numpy(synth.uniform(9, "rimg", (3, 3, hw[0], hw[1]), -1.0, 1.0))
+    sd = {"encoder." + k: torch.from_numpy(v) for k, v in np_sd.items()}
+    with torch.no_grad():
+        want_feat = RO.resnet_trunk(sd, model_name, x)
+        want = RO.resnet_encoder(sd, model_name, x)
+        got_feat = enc.trunk(x.to(DEV)).cpu()
+        got = enc(x.to(DEV)).cpu()
+    assert got.shape == (3, 64)
+    # bf16 activations through 18-50 layers: a few 1e-2 relative to the feature scale
+    assert float((got_feat - want_feat).abs().max()) <= 4e-2 * float(want_feat.abs().max())
+    assert float((got - want).abs().max()) <= 4e-2 * max(1.0, float(want.abs().max()))
+    enc.train()
+    with pytest.raises(NotImplementedError):
+        enc(x.to(DEV))
