@@ -116,7 +116,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // The weight stream is software-pipelined: while the FMAs of one batch of PF rows run, the
 // loads of the next batch are already in flight (two register sets, counted vmcnt by the
 // compiler), so one wave per SIMD keeps ~PF 16-byte loads per lane outstanding.
-constexpr int PF = 16;
+constexpr int PF = 8;
 
 template <int R, int NV>   // NV = 4 (float4: LSTM gates) or 2 (float2: vocabulary projection)
 struct WVec;
@@ -144,6 +144,37 @@ __device__ __forceinline__ void fma_rows(float4 (&acc)[R], const float4 (&w)[PF]
     }
 }
 
+template <typename VT>
+__device__ __forceinline__ void load_batch(VT (&w)[PF], const float* __restrict__ Wcol, size_t ldw) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) w[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)i * ldw);
+}
+
+// matvec whose first batch (rows 0..PF-1) was loaded earlier by load_batch (prefetch across a barrier).
+template <int R, typename VT>
+__device__ __forceinline__ void matvec_pre(VT (&acc)[R], VT (&wa)[PF], const float* __restrict__ Wcol, size_t ldw,
+                                           const float* xs, int xstride, int H) {
+    VT wb[PF];
+    int k = 0;
+    for (; k + 2 * PF < H; k += 2 * PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) wb[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)(k + PF + i) * ldw);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_rows<R>(acc, wa, xs, xstride, k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) wa[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)(k + 2 * PF + i) * ldw);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_rows<R>(acc, wb, xs, xstride, k + PF);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) wb[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)(k + PF + i) * ldw);
+    __builtin_amdgcn_sched_barrier(0);
+    fma_rows<R>(acc, wa, xs, xstride, k);
+    fma_rows<R>(acc, wb, xs, xstride, k + PF);
+}
+
 template <int R, typename VT>
 __device__ __forceinline__ void matvec(VT (&acc)[R], const float* __restrict__ Wcol, size_t ldw, const float* xs,
                                        int xstride, int H) {   // H = number of k (multiple of 32), xstride = row stride of xs
@@ -153,7 +184,7 @@ __device__ __forceinline__ void matvec(VT (&acc)[R], const float* __restrict__ W
 #pragma unroll
     for (int i = 0; i < PF; ++i) wa[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)i * ldw);
     int k = 0;
-    for (; k + 2 * PF < H; k += 2 * PF) {                 // H % 32 == 0
+    for (; k + 2 * PF < H; k += 2 * PF) {                 // H % (2*PF) == 0
 #pragma unroll
         for (int i = 0; i < PF; ++i) wb[i] = *reinterpret_cast<const VT*>(Wcol + (size_t)(k + PF + i) * ldw);
         __builtin_amdgcn_sched_barrier(0);                // keep the batch of loads ahead of the FMAs
@@ -249,10 +280,10 @@ __device__ __forceinline__ void lstm_layers(const StepWeights& w, const int (&to
 // deterministic.  Optionally writes raw logits to global (lp[r] != null), keeps logit/temperature
 // in LDS (lg != null), and returns each thread's running (max, first index); upper-half threads
 // return -inf.  Contains __syncthreads(); every thread of the workgroup must call it.
-template <int R>
+template <int R, bool PRE = false>
 __device__ __forceinline__ void project(const StepWeights& w, const float* h_top, float* const (&lp)[R],
                                         float* lg, bool use_temp, float temperature, float (&best)[R],
-                                        int (&besti)[R], float* psum, int tid) {
+                                        int (&besti)[R], float* psum, int tid, float4 (*pre)[PF] = nullptr) {
     const int half = tid >> 7, c4 = (tid & 127) * 4;
     const int Hh = w.H >> 1;
 #pragma unroll
@@ -262,7 +293,10 @@ __device__ __forceinline__ void project(const StepWeights& w, const float* h_top
         const float4 bb = half == 0 ? *reinterpret_cast<const float4*>(w.boutP + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = bb;
-        matvec<R, float4>(acc, w.WoutT + (size_t)half * Hh * w.Vp + v0, (size_t)w.Vp, h_top + half * Hh, w.H, Hh);
+        if (PRE && v0 == c4)      // first pass: rows 0..PF-1 were prefetched before the LSTM step
+            matvec_pre<R, float4>(acc, *pre, w.WoutT + (size_t)half * Hh * w.Vp + v0, (size_t)w.Vp, h_top + half * Hh, w.H, Hh);
+        else
+            matvec<R, float4>(acc, w.WoutT + (size_t)half * Hh * w.Vp + v0, (size_t)w.Vp, h_top + half * Hh, w.H, Hh);
         if (half == 1) {
 #pragma unroll
             for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(psum + ((size_t)r * 128 + (tid & 127)) * 4) = acc[r];
@@ -356,6 +390,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
 #pragma unroll
         for (int k = 0; k < KR; ++k) wres[k] = *reinterpret_cast<const float4*>(w.WhhT[0] + (size_t)k * 4 * H + 4 * jj);
     }
+    float4 genc_reg = make_float4(0.f, 0.f, 0.f, 0.f);     // image half of the layer-0 gates: constant over the loop
+    if (KR + KL > 0) genc_reg = *reinterpret_cast<const float4*>(w.Genc + (size_t)grow[0] * 4 * H + 4 * jj);
     if (KL > 0) {
         const float4* src = reinterpret_cast<const float4*>(w.WhhT[0] + (size_t)KR * 4 * H);
         for (int idx = tid; idx < KL * H; idx += NT) reinterpret_cast<float4*>(wl)[idx] = src[idx];
@@ -371,15 +407,19 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
             int tk = p.forced ? p.forced[(size_t)grow[r] * T + t] : tok_s[r];
             tok[r] = min(max(tk, 0), V - 1);
         }
+        float4 pre[PF];                                   // first batch of the projection stream (fast path)
+        if (KR + KL > 0)
+            load_batch<float4>(pre, w.WoutT + (size_t)(tid >> 7) * (H >> 1) * w.Vp + (tid & 127) * 4, (size_t)w.Vp);
         if (KR + KL > 0) {
             // R == 1, L == 1, H <= NT: one LSTM layer, thread tid = hidden unit
             const size_t G = 4 * (size_t)H;
             const float* h_old = hs + (size_t)par * H;
             float* h_new = hs + (size_t)(par ^ 1) * H;
             if (tid < H) {
+                // the token-dependent row of P is only needed at the end of the chain: its L2 latency hides
+                // behind the 96 resident rows (the sum starts from the image half, which never changes)
                 const float4 a = *reinterpret_cast<const float4*>(w.P + (size_t)tok[0] * G + 4 * tid);
-                const float4 e = *reinterpret_cast<const float4*>(w.Genc + (size_t)grow[0] * G + 4 * tid);
-                float4 acc[1] = {make_float4(a.x + e.x, a.y + e.y, a.z + e.z, a.w + e.w)};
+                float4 acc[1] = {genc_reg};
 #pragma unroll
                 for (int k4 = 0; k4 < KR; k4 += 4) {
                     const float4 xa = *reinterpret_cast<const float4*>(h_old + k4);
@@ -406,6 +446,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
                     }
                 }
                 matvec<1, float4>(acc, w.WhhT[0] + (size_t)(KR + KL) * G + 4 * tid, G, h_old + KR + KL, H, H - KR - KL);
+                acc[0].x += a.x; acc[0].y += a.y; acc[0].z += a.z; acc[0].w += a.w;
                 const float ig = sigmoidf_(acc[0].x), fg = sigmoidf_(acc[0].y);
                 const float gg = tanhf(acc[0].z), og = sigmoidf_(acc[0].w);
                 const float cn = fg * cs[tid] + ig * gg;
@@ -425,8 +466,12 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
             lp[r] = (p.logits && row0 + r < B) ? p.logits + ((size_t)(row0 + r) * T + t) * V : nullptr;
         float best[R];
         int besti[R];
-        project<R>(w, h_top, lp, p.select == I2L_SELECT_SOFTMAX ? lg : nullptr, p.use_temp != 0, p.temperature,
-                   best, besti, psum, tid);
+        if (KR + KL > 0)
+            project<R, true>(w, h_top, lp, p.select == I2L_SELECT_SOFTMAX ? lg : nullptr, p.use_temp != 0,
+                             p.temperature, best, besti, psum, tid, &pre);
+        else
+            project<R>(w, h_top, lp, p.select == I2L_SELECT_SOFTMAX ? lg : nullptr, p.use_temp != 0, p.temperature,
+                       best, besti, psum, tid);
         block_argmax<R>(best, besti, redv, redi, tid);
         if (p.select == I2L_SELECT_SOFTMAX) {
             // argmax(softmax(x)): probabilities in fp32 as torch.softmax (exp(x - max) / sum), first index wins
@@ -714,7 +759,7 @@ StepWeights step_weights(const Layout& lo, const char* base, int V, int H, int L
     return w;
 }
 
-constexpr int RES_KR = 64, RES_KL = 32;   // resident rows of WhhT[0]: registers / LDS (fast path)
+constexpr int RES_KR = 76, RES_KL = 36;   // resident rows of WhhT[0]: registers / LDS (fast path)
 
 size_t decode_lds_bytes(int R, int L, int H, int Vp, int select, int KL = 0) {
     size_t floats = (size_t)3 * L * R * H + 4 * R + 4 * R + R + R + 4 + (size_t)R * 512 + (size_t)KL * 4 * H;
