@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     int tiles_x, int n_chunks) {
     constexpr int CO_BLK = 32 * NTL;
     constexpr int W_SLAB = (CI_BLK / 2) * 9 * 2 * CO_BLK;          // floats of packed weights per chunk
-    __shared__ __attribute__((aligned(16))) float in_s[CI_BLK * M_CH];
+    constexpr int OUT_S = CO_BLK * 65;                             // pooled output tile staged for coalesced stores
+    constexpr int IN_S = CI_BLK * M_CH > OUT_S ? CI_BLK * M_CH : OUT_S;
+    __shared__ __attribute__((aligned(16))) float in_s[IN_S];
     __shared__ __attribute__((aligned(16))) float w_s[W_SLAB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,24 +97,58 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* xb = x + (size_t)b * Cin * H * W;
     const float* wp_cb = wpack + (size_t)cb * n_chunks * W_SLAB;
 
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    // Per-thread staging plan, computed once: element e of this thread goes to LDS offset loff[e] and comes
+    // from global offset goff[e] inside the chunk's first channel plane (ok bit e: inside the image).
+    constexpr int NE = (CI_BLK * M_IR * M_IC + 255) / 256;
+    constexpr int NWV = (W_SLAB / 4 + 255) / 256;
+    int loff[NE], goff[NE], cch[NE];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int idx = tid + e * 256;
+        const int c = idx / (M_IR * M_IC);
+        const int rem = idx - c * (M_IR * M_IC);
+        const int r = rem / M_IC, col = rem - r * M_IC;
+        const int iy = y0 - 1 + r, ix = x0 - 1 + col;
+        loff[e] = c * M_CH + r * M_ST + col;
+        goff[e] = (c * H + iy) * W + ix;
+        cch[e] = c;
+        if (idx < CI_BLK * M_IR * M_IC && iy >= 0 && iy < H && ix >= 0 && ix < W) okmask |= 1u << e;
+        if (idx >= CI_BLK * M_IR * M_IC) loff[e] = -1;
+    }
+    float xin[NE];
+    float4 win[NWV];
+    auto fetch = [&](int chunk) {          // global -> registers (latency overlaps the MFMA loop of the previous chunk)
         const int ci0 = chunk * CI_BLK;
-        __syncthreads();                                           // previous chunk's operand reads are done
-        // ---- stage the input patch: CI_BLK x 10 x 34, zero outside the image / beyond Cin
-        for (int idx = tid; idx < CI_BLK * M_IR * M_IC; idx += 256) {
-            const int c = idx / (M_IR * M_IC);
-            const int rem = idx - c * (M_IR * M_IC);
-            const int r = rem / M_IC, col = rem - r * M_IC;
-            const int iy = y0 - 1 + r, ix = x0 - 1 + col, ci = ci0 + c;
-            float v = 0.f;
-            if (ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v = xb[((size_t)ci * H + iy) * W + ix];
-            in_s[c * M_CH + r * M_ST + col] = v;
-        }
-        // ---- stage the packed weight slab of this chunk (contiguous copy)
+        const float* xc = xb + (size_t)ci0 * H * W;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            xin[e] = (((okmask >> e) & 1u) && ci0 + cch[e] < Cin) ? xc[goff[e]] : 0.f;
         const float4* wsrc = reinterpret_cast<const float4*>(wp_cb + (size_t)chunk * W_SLAB);
-        for (int idx = tid; idx < W_SLAB / 4; idx += 256) reinterpret_cast<float4*>(w_s)[idx] = wsrc[idx];
+#pragma unroll
+        for (int e = 0; e < NWV; ++e) {
+            const int idx = tid + e * 256;
+            win[e] = idx < W_SLAB / 4 ? wsrc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {                  // registers -> LDS
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (loff[e] >= 0) in_s[loff[e]] = xin[e];
+#pragma unroll
+        for (int e = 0; e < NWV; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < W_SLAB / 4) reinterpret_cast<float4*>(w_s)[idx] = win[e];
+        }
+    };
+
+    fetch(0);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        __syncthreads();                                           // previous chunk's operand reads are done
+        commit();
         __syncthreads();
-        // ---- (CI_BLK/2) x 9 k-steps, 4 MFMAs each
+        if (chunk + 1 < n_chunks) fetch(chunk + 1);                // in flight during the MFMAs below
+        // ---- (CI_BLK/2) x 9 k-steps, 2*NTL MFMAs each
 #pragma unroll
         for (int cp = 0; cp < CI_BLK / 2; ++cp) {
 #pragma unroll
@@ -134,6 +170,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 
     // ---- epilogue.  C/D layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5):
     // registers 4q..4q+3 of a lane are the 2x2 quad of pooled column pp = 2q + h.
+    // Fast store path (inference, interior tiles): pooled tile -> LDS [channel][4 rows x 16 cols] -> 64-byte runs.
+    const int py0 = y0 >> 1, px0 = x0 >> 1;
+    if (POOL && amax == nullptr && (Wp & 3) == 0 && py0 + 4 <= Hp && px0 + 16 <= Wp && (cb + 1) * CO_BLK <= Cout) {
+        __syncthreads();                                           // all operand reads of in_s are done
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) {
+            const float bv = bias[cb * CO_BLK + n * 32 + i];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
+                                          fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
+                    in_s[(n * 32 + i) * 65 + (wy * 2 + m) * 16 + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < CO_BLK * 16; idx += 256) {       // (channel, row, 4-column group)
+            const int x4 = idx & 3, py = (idx >> 2) & 3, co_l = idx >> 4;
+            const float* sp = &in_s[co_l * 65 + py * 16 + 4 * x4];
+            float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * CO_BLK + co_l) * Hp + py0 + py) * Wp + px0 + 4 * x4) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NTL; ++n) {
         const int co = cb * CO_BLK + n * 32 + i;
