@@ -32,11 +32,14 @@ namespace {
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int M_TR = 8, M_TC = 32;             // conv rows / cols per workgroup
-constexpr int M_IR = M_TR + 2;                 // 10 input rows
-constexpr int M_IC = M_TC + 2;                 // 34 input cols
-constexpr int M_ST = 48;                       // LDS row stride (floats), == 16 mod 32
-constexpr int M_CH = M_IR * M_ST;              // 480 floats per staged channel
+// Workgroup tile = (4/WX * 4) conv rows x (WX * 16) conv cols; the 4 waves sit WX across, 4/WX down.
+// WX = 2: 8 x 32 (default), WX = 1: 16 x 16, WX = 4: 4 x 64 -- picked per launch to waste the fewest tiles.
+template <int WX> struct Tile {
+    static constexpr int TR = (4 / WX) * 4, TC = WX * 16;      // conv rows / cols per workgroup
+    static constexpr int IR = TR + 2, IC = TC + 2;             // staged input rows / cols (1-pixel halo)
+    static constexpr int ST = WX == 4 ? 80 : 48;               // LDS row stride (floats), == 16 mod 32, >= IC
+    static constexpr int CH = IR * ST;                         // floats per staged channel
+};
 
 // wpack[co_blk][chunk][cp][tap][h][CO_BLK]: value = w[co_blk*CO_BLK + co][chunk*CI_BLK + 2*cp + h][tap], 0 outside.
 // flip != 0 packs the weights of the DATA-GRADIENT convolution: w is the forward filter (Cin_f = Cout, Cout_f = Cin),
@@ -61,11 +64,14 @@ __global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __r
 
 // POOL = true : y = maxpool2(relu(conv + bias)) (B,Cout,Hp,Wp), optional argmax (0..3 = 2*dy+dx, first max wins)
 // POOL = false: y = conv (B,Cout,H,W), no bias / activation (the data-gradient convolution of the backward pass)
-template <int CI_BLK, int NTL, bool POOL>      // NTL = 32-channel N-tiles per wave (workgroup covers CO_BLK = 32*NTL channels)
+template <int CI_BLK, int NTL, bool POOL, int WX>      // NTL = 32-channel N-tiles per wave (workgroup covers CO_BLK = 32*NTL channels)
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
     float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
     int tiles_x, int n_chunks) {
+    constexpr int M_TR = Tile<WX>::TR, M_TC = Tile<WX>::TC, M_IR = Tile<WX>::IR, M_IC = Tile<WX>::IC;
+    constexpr int M_ST = Tile<WX>::ST, M_CH = Tile<WX>::CH;
+    constexpr int PR = M_TR / 2, PC = M_TC / 2;                    // pooled tile (PR * PC == 64)
     constexpr int CO_BLK = 32 * NTL;
     constexpr int W_SLAB = (CI_BLK / 2) * 9 * 2 * CO_BLK;          // floats of packed weights per chunk
     constexpr int OUT_S = CO_BLK * 65;                             // pooled output tile staged for coalesced stores
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     __shared__ __attribute__((aligned(16))) float w_s[W_SLAB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wy = wave >> 1, wx = wave & 1;
+    const int wy = wave / WX, wx = wave % WX;
     const int cb = blockIdx.x;                                     // channel block (fastest: shares the input patch in L2)
     const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
     const int b = blockIdx.z;
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     // registers 4q..4q+3 of a lane are the 2x2 quad of pooled column pp = 2q + h.
     // Fast store path (inference, interior tiles): pooled tile -> LDS [channel][4 rows x 16 cols] -> 64-byte runs.
     const int py0 = y0 >> 1, px0 = x0 >> 1;
-    if (POOL && amax == nullptr && (Wp & 3) == 0 && py0 + 4 <= Hp && px0 + 16 <= Wp && (cb + 1) * CO_BLK <= Cout) {
+    if (POOL && amax == nullptr && (Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
         __syncthreads();                                           // all operand reads of in_s are done
 #pragma unroll
         for (int n = 0; n < NTL; ++n) {
@@ -183,13 +189,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                 for (int q = 0; q < 4; ++q) {
                     const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
                                           fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
-                    in_s[(n * 32 + i) * 65 + (wy * 2 + m) * 16 + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
+                    in_s[(n * 32 + i) * 65 + (wy * 2 + m) * PC + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
                 }
         }
         __syncthreads();
         for (int idx = tid; idx < CO_BLK * 16; idx += 256) {       // (channel, row, 4-column group)
-            const int x4 = idx & 3, py = (idx >> 2) & 3, co_l = idx >> 4;
-            const float* sp = &in_s[co_l * 65 + py * 16 + 4 * x4];
+            constexpr int XG = PC / 4;
+            const int x4 = idx % XG, py = (idx / XG) % PR, co_l = idx >> 4;
+            const float* sp = &in_s[co_l * 65 + py * PC + 4 * x4];
             float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
             *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * CO_BLK + co_l) * Hp + py0 + py) * Wp + px0 + 4 * x4) = v;
         }
@@ -345,15 +352,45 @@ __global__ __launch_bounds__(256) void conv3x3_relu_pool2_direct(
 int mfma_ci_blk(int Cin) { return Cin <= 4 ? 4 : 8; }
 int mfma_co_blk(int Cout) { return Cout % 64 == 0 ? 64 : 32; }
 
-template <int CI_BLK, int NTL>
-void launch_mfma(bool pool, dim3 grid, hipStream_t s, const float* x, const float* wpack, const float* bias, float* y,
-                 unsigned char* amax, int Cin, int H, int W, int Cout, int Hp, int Wp, int tiles_x, int n_chunks) {
+template <int CI_BLK, int NTL, int WX>
+void launch_mfma_wx(bool pool, dim3 grid, hipStream_t s, const float* x, const float* wpack, const float* bias, float* y,
+                    unsigned char* amax, int Cin, int H, int W, int Cout, int Hp, int Wp, int tiles_x, int n_chunks) {
     if (pool)
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<CI_BLK, NTL, true>), grid, dim3(256), 0, s, x, wpack, bias, y, amax, Cin,
-                           H, W, Cout, Hp, Wp, tiles_x, n_chunks);
-    else
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<CI_BLK, NTL, false>), grid, dim3(256), 0, s, x, wpack, bias, y, amax,
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<CI_BLK, NTL, true, WX>), grid, dim3(256), 0, s, x, wpack, bias, y, amax,
                            Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+    else
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<CI_BLK, NTL, false, WX>), grid, dim3(256), 0, s, x, wpack, bias, y, amax,
+                           Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+}
+
+// tile shape with the fewest wasted positions for a rows x cols output plane (ties: the default 8 x 32)
+int pick_wx(int rows, int cols) {
+    int best = 2;
+    long bestw = -1;
+    const int cand[3] = {2, 1, 4};
+    for (int c = 0; c < 3; ++c) {
+        const int wx = cand[c], tr = (4 / wx) * 4, tc = wx * 16;
+        const long cover = (long)i2l_cdiv(rows, tr) * tr * i2l_cdiv(cols, tc) * tc;
+        if (bestw < 0 || cover < bestw) { bestw = cover; best = wx; }
+    }
+    return best;
+}
+
+template <int CI_BLK, int NTL>
+int launch_mfma(bool pool, int co_blocks, int B, hipStream_t s, const float* x, const float* wpack, const float* bias,
+                float* y, unsigned char* amax, int Cin, int H, int W, int Cout, int Hp, int Wp, int n_chunks) {
+    // pooled: tiles cover the conv positions that feed a pooled output (floor pooling drops an odd last
+    // row/col); plain: every position
+    const int rows = pool ? 2 * Hp : H, cols = pool ? 2 * Wp : W;
+    const int wx = pick_wx(rows, cols);
+    const int tr = (4 / wx) * 4, tc = wx * 16;
+    const int tiles_x = i2l_cdiv(cols, tc), tiles_y = i2l_cdiv(rows, tr);
+    if ((long long)tiles_x * tiles_y > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
+    dim3 grid(co_blocks, tiles_x * tiles_y, B);
+    if (wx == 2) launch_mfma_wx<CI_BLK, NTL, 2>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+    else if (wx == 1) launch_mfma_wx<CI_BLK, NTL, 1>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+    else launch_mfma_wx<CI_BLK, NTL, 4>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+    return I2L_OK;
 }
 
 // One 3x3 / pad 1 convolution launch.  pool: fused bias+ReLU+maxpool2 (+argmax); !pool: plain full-resolution
@@ -385,16 +422,12 @@ int run_conv(bool pool, const float* x, const float* w, const float* bias, float
         hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(i2l_cdiv(total, 256)), dim3(256), 0, s, w, wpack, Cin, Cout,
                            cbk, n_chunks, cob, total, pool ? 0 : 1);
         I2L_CHECK_LAUNCH();
-        // pooled: tiles cover the conv positions that feed a pooled output (floor pooling drops an odd last
-        // row/col); plain: every position
-        const int rows = pool ? 2 * Hp : H, cols = pool ? 2 * Wp : W;
-        const int tiles_x = i2l_cdiv(cols, M_TC), tiles_y = i2l_cdiv(rows, M_TR);
-        if ((long long)tiles_x * tiles_y > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
-        dim3 grid(co_blocks, tiles_x * tiles_y, B);
-        if (cbk == 4 && cob == 32) launch_mfma<4, 1>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
-        else if (cbk == 4) launch_mfma<4, 2>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
-        else if (cob == 32) launch_mfma<8, 1>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
-        else launch_mfma<8, 2>(pool, grid, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks);
+        int rc;
+        if (cbk == 4 && cob == 32) rc = launch_mfma<4, 1>(pool, co_blocks, B, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, n_chunks);
+        else if (cbk == 4) rc = launch_mfma<4, 2>(pool, co_blocks, B, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, n_chunks);
+        else if (cob == 32) rc = launch_mfma<8, 1>(pool, co_blocks, B, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, n_chunks);
+        else rc = launch_mfma<8, 2>(pool, co_blocks, B, s, x, wpack, bias, y, amax, Cin, H, W, Cout, Hp, Wp, n_chunks);
+        if (rc != I2L_OK) return rc;
         I2L_CHECK_LAUNCH();
         return I2L_OK;
     }
