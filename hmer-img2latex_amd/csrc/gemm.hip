@@ -18,7 +18,9 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, LDP = BK + 1;
+constexpr int BM = 64, BN = 64, BK = 64, LDP = BK + 1;
+constexpr int NLD = BM * BK / 4 / 256;      // float4 loads per thread per operand tile
+constexpr int KQ = BK / 4;                  // float4 chunks along k
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int perm_col(int n, int perm_h) {
@@ -36,51 +38,60 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, 
     *c = g.accumulate ? *c + v : v;
 }
 
-// Stage a (64 rows x 32 k) operand tile into LDS (row stride 33), zero-filled outside [rows) x [kbeg,kend).
+// A (64 rows x 32 k) operand tile moves global -> registers -> LDS (row stride 33), zero-filled outside
+// [rows) x [kbeg,kend).  The two halves are separate so the global loads of tile t+1 can be in flight
+// while the MFMAs of tile t run (the LDS write happens after the barrier that ends tile t).
 template <bool KC, bool VEC>
-__device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__ src, long ld, int row0, int rows,
-                                           int k0, int kend, int tid) {
-    if (KC) {
+__device__ __forceinline__ void load_tile(float (&v)[NLD][4], const float* __restrict__ src, long ld, int row0, int rows,
+                                          int k0, int kend, int tid) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 256;              // 64 rows x 8 float4 along k
-            const int row = idx >> 3, c4 = (idx & 7) * 4;
-            const int k = k0 + c4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+        if (KC) {                                       // 64 rows x KQ float4 along k
+            const int row = idx / KQ, k = k0 + (idx % KQ) * 4;
             if (row0 + row < rows) {
                 const float* p = src + (size_t)(row0 + row) * ld + k;
                 if (VEC && k + 3 < kend) {
                     const float4 t = *reinterpret_cast<const float4*>(p);
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (k + e < kend) v[e] = p[e];
+                        if (k + e < kend) v[i][e] = p[e];
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dst[row * LDP + c4 + e] = v[e];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 256;              // 32 k x 16 float4 along the row index
-            const int kk = idx >> 4, r4 = (idx & 15) * 4;
-            const int k = k0 + kk;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
+        } else {                                        // BK k x 16 float4 along the row index
+            const int k = k0 + (idx >> 4), r4 = (idx & 15) * 4;
             if (k < kend) {
                 const float* p = src + (size_t)k * ld + row0 + r4;
                 if (VEC && row0 + r4 + 3 < rows) {
                     const float4 t = *reinterpret_cast<const float4*>(p);
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (row0 + r4 + e < rows) v[e] = p[e];
+                        if (row0 + r4 + e < rows) v[i][e] = p[e];
                 }
             }
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* dst, const float (&v)[NLD][4], int tid) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(r4 + e) * LDP + kk] = v[e];
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        if (KC) {
+            const int row = idx / KQ, c4 = (idx % KQ) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[row * LDP + c4 + e] = v[i][e];
+        } else {
+            const int kk = idx >> 4, r4 = (idx & 15) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(r4 + e) * LDP + kk] = v[i][e];
         }
     }
 }
@@ -106,10 +117,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, float* __restrict
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    float va[NLD][4], vw[NLD][4];
+    load_tile<A_KC, VEC>(va, Az, g.lda, m0, g.M, kbeg, kend, tid);
+    load_tile<W_KC, VEC>(vw, Wz, g.ldw, n0, g.N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage_tile<A_KC, VEC>(As, Az, g.lda, m0, g.M, k0, kend, tid);
-        stage_tile<W_KC, VEC>(Ws, Wz, g.ldw, n0, g.N, k0, kend, tid);
+        store_tile<A_KC>(As, va, tid);
+        store_tile<W_KC>(Ws, vw, tid);
         __syncthreads();
+        if (k0 + BK < kend) {                           // next tile's loads fly during the MFMAs
+            load_tile<A_KC, VEC>(va, Az, g.lda, m0, g.M, k0 + BK, kend, tid);
+            load_tile<W_KC, VEC>(vw, Wz, g.ldw, n0, g.N, k0 + BK, kend, tid);
+        }
         const float* ap = &As[(wm * 32 + li) * LDP + lk];
         const float* wp = &Ws[(wn * 32 + li) * LDP + lk];
 #pragma unroll
