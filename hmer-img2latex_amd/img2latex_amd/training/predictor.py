@@ -1,0 +1,152 @@
+"""Predictor with the reference's surface (img2latex/training/predictor.py:20-394) on the HIP path.
+
+Checkpoint compatibility: ``from_checkpoint`` reads the dict the reference's
+``Trainer.save_checkpoint`` writes (trainer.py:209-224: ``model_state_dict``, ``config``,
+``tokenizer_config{token_to_id, special_tokens, max_sequence_length}``) and rebuilds model and
+token table exactly as predictor.py:80-129 does.  The greedy loop of ``predict_batch``
+(predictor.py:283-358) runs as ONE persistent kernel launch (I2L_STOP_STICKY + argmax of softmax).
+
+Out of scope here (host-side preprocessing): image files / PIL images /
+resizing -- inputs are tensors already shaped (C,H,W) or (B,C,H,W) for the model.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+from .. import _lib
+from ..model import Seq2SeqModel
+
+DEFAULT_SPECIAL_TOKENS = {"PAD": "<PAD>", "START": "<START>", "END": "<END>", "UNK": "<UNK>"}   # tokenizer.py:36-41
+
+
+class TokenTable:
+    """The part of LaTeXTokenizer the predictor touches: id maps, special ids, decode()
+    (tokenizer.py:68-78,166-192).  String <-> id only; fitting a vocabulary is out of scope."""
+
+    def __init__(self, token_to_id: Optional[Dict[str, int]] = None, special_tokens: Optional[Dict[str, str]] = None,
+                 max_sequence_length: int = 141):
+        self.special_tokens = dict(special_tokens or DEFAULT_SPECIAL_TOKENS)
+        if token_to_id is None:
+            token_to_id = {tok: i for i, tok in enumerate(self.special_tokens.values())}
+        self.token_to_id = dict(token_to_id)
+        self.id_to_token = {i: t for t, i in self.token_to_id.items()}
+        self.vocab_size = len(self.token_to_id)
+        self.max_sequence_length = max_sequence_length
+        self.pad_token_id = self.token_to_id[self.special_tokens["PAD"]]
+        self.start_token_id = self.token_to_id[self.special_tokens["START"]]
+        self.end_token_id = self.token_to_id[self.special_tokens["END"]]
+        self.unk_token_id = self.token_to_id[self.special_tokens["UNK"]]
+
+    def decode(self, ids: Sequence[int], skip_special_tokens: bool = True) -> str:
+        special = {self.token_to_id[t] for t in self.special_tokens.values()} if skip_special_tokens else set()
+        return " ".join(self.id_to_token.get(int(i), self.special_tokens["UNK"]) for i in ids if int(i) not in special)
+
+    def config(self) -> Dict:
+        return {"token_to_id": self.token_to_id, "special_tokens": self.special_tokens,
+                "max_sequence_length": self.max_sequence_length}
+
+
+def model_from_checkpoint_config(config: Dict, vocab_size: int) -> Seq2SeqModel:
+    """predictor.py:83-126: config["model"] -> Seq2SeqModel constructor arguments."""
+    model_config = config.get("model", {})
+    model_type = model_config.get("name", "cnn_lstm")
+    enc = dict(model_config.get("encoder", {}).get("cnn" if model_type == "cnn_lstm" else "resnet", {}))
+    enc["embedding_dim"] = model_config.get("embedding_dim", 256)
+    return Seq2SeqModel(model_type=model_type, vocab_size=vocab_size, encoder_params=enc,
+                        decoder_params=model_config.get("decoder", {}))
+
+
+def save_checkpoint(path: str, model: Seq2SeqModel, tokenizer: TokenTable, config: Dict, epoch: int = 0, step: int = 0,
+                    metrics: Optional[Dict] = None, optimizer_state_dict: Optional[Dict] = None) -> None:
+    """The dict of trainer.py:209-224, readable by the reference's Predictor.from_checkpoint / load_checkpoint."""
+    torch.save({"epoch": epoch, "step": step,
+                "model_state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": optimizer_state_dict or {}, "metrics": metrics or {}, "config": config,
+                "tokenizer_config": tokenizer.config()}, path)
+
+
+class Predictor:
+    def __init__(self, model: Seq2SeqModel, tokenizer, device: Optional[torch.device] = None,
+                 model_type: str = "cnn_lstm"):
+        self.device = torch.device("cuda") if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("img2latex_amd: Predictor runs on a ROCm device only (no CPU fallback)")
+        self.model = model.to(self.device)
+        self.tokenizer = tokenizer
+        self.model_type = model_type
+        self.model.eval()                                                   # predictor.py:55
+
+    @classmethod
+    def from_checkpoint(cls, checkpoint_path: str, device: Optional[torch.device] = None) -> "Predictor":
+        checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        config = checkpoint.get("config", {})
+        tcfg = checkpoint.get("tokenizer_config", {})
+        tokenizer = TokenTable(tcfg.get("token_to_id"), tcfg.get("special_tokens"), tcfg.get("max_sequence_length", 141))
+        model = model_from_checkpoint_config(config, tokenizer.vocab_size)
+        model.load_state_dict(checkpoint["model_state_dict"])               # predictor.py:129, strict
+        return cls(model=model, tokenizer=tokenizer, device=device,
+                   model_type=config.get("model", {}).get("name", "cnn_lstm"))
+
+    # ------------------------------------------------------------------
+    def _as_batch(self, images) -> torch.Tensor:
+        if isinstance(images, torch.Tensor):
+            t = images if images.dim() == 4 else images.unsqueeze(0)
+        else:
+            items = []
+            for im in images:
+                if not isinstance(im, torch.Tensor):
+                    raise TypeError("img2latex_amd Predictor takes image TENSORS already sized for the model; file / "
+                                    "PIL / numpy preprocessing (predictor.py:396-499) is host-side work outside this path")
+                items.append(im if im.dim() == 3 else im.squeeze(0))
+            t = torch.stack(items)
+        return t.to(self.device, dtype=torch.float32).contiguous()
+
+    def predict_batch_ids(self, images, max_length: int = 141, temperature: float = 1.0) -> List[List[int]]:
+        """Token ids of the batched greedy loop (predictor.py:254-361): START kept, cut before the first END."""
+        x = self._as_batch(images)
+        with torch.no_grad():
+            enc = self.model.encoder(x)
+            ids, _ = self.model.greedy_ids(enc, self.tokenizer.start_token_id, self.tokenizer.end_token_id, max_length,
+                                           temperature, stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX)
+        end, start = self.tokenizer.end_token_id, self.tokenizer.start_token_id
+        out = []
+        for row in ids.cpu().tolist():
+            row = [t for t in row if t >= 0]
+            out.append([start] + (row[: row.index(end)] if end in row else row))
+        return out
+
+    def predict_batch(self, images, beam_size: int = 0, max_length: int = 141, temperature: float = 1.0,
+                      top_k: int = 0, top_p: float = 0.0, batch_size: int = 16) -> List[str]:
+        """predictor.py:205-394.  As in the reference beam_size is clamped to 0 (:231-235); sampling
+        (top_k / top_p > 0, :330-331) is not built -- the deterministic branch (:333) is."""
+        if top_k > 0 or top_p > 0.0:
+            raise NotImplementedError("img2latex_amd Predictor: multinomial sampling (top_k/top_p) is not built")
+        x = self._as_batch(images)
+        results: List[str] = []
+        start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
+        for i in range(0, x.shape[0], batch_size):
+            for seq in self.predict_batch_ids(x[i:i + batch_size], max_length, temperature):
+                if seq and seq[0] == start:                                 # :384-388
+                    seq = seq[1:]
+                if seq and seq[-1] == end:
+                    seq = seq[:-1]
+                results.append(self.tokenizer.decode(seq))
+        return results
+
+    def predict(self, image, beam_size: int = 0, max_length: int = 141, temperature: float = 1.0, top_k: int = 0,
+                top_p: float = 0.0) -> str:
+        """predictor.py:139-203: one image through Seq2SeqModel.inference (greedy; beam clamped to 0)."""
+        x = self._as_batch(image)
+        start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
+        with torch.no_grad():
+            seq = self.model.inference(image=x, start_token_id=start, end_token_id=end, max_length=max_length,
+                                       beam_size=0, temperature=temperature, top_k=top_k, top_p=top_p)
+        if seq and isinstance(seq[0], list):
+            seq = seq[0]
+        if seq and seq[0] == start:
+            seq = seq[1:]
+        if seq and seq[-1] == end:
+            seq = seq[:-1]
+        return self.tokenizer.decode(seq)

@@ -106,3 +106,32 @@ class TrainStep:
         self.apply()
         count = self.flat_grads[self.n + 1]
         return dict(loss=self.flat_grads[self.n] / count.clamp(min=1.0), total_norm=self.stats[0], count=count)
+
+    # ------------------------------------------------------------------ checkpoint compatibility
+    def optimizer_state_dict(self) -> Dict:
+        """torch.optim.Adam.state_dict() layout (what trainer.py:213 stores): resuming in the reference works."""
+        state, params = {}, []
+        for i, (name, p) in enumerate(self.model.named_parameters()):
+            o = self.offsets[name]
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).detach().cpu().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view_as(p).detach().cpu().clone()}
+            params.append(i)
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": params}
+        return {"state": state if self.step_count > 0 else {}, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: Dict) -> None:
+        """Inverse of the above (trainer.py:255, resume from a reference checkpoint)."""
+        names = [n for n, _ in self.model.named_parameters()]
+        for i, st in sd.get("state", {}).items():
+            name = names[int(i)]
+            p = dict(self.model.named_parameters())[name]
+            o = self.offsets[name]
+            self.exp_avg[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
+            self.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+            self.step_count = int(float(st["step"]))
+        g = sd.get("param_groups", [{}])[0]
+        self.lr = g.get("lr", self.lr)
+        self.weight_decay = g.get("weight_decay", self.weight_decay)

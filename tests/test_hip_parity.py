@@ -325,3 +325,41 @@ def test_resnet_encoder_vs_oracle(model_name, hw):
     enc.train()
     with pytest.raises(NotImplementedError):
         enc(x.to(DEV))
+
+
+def test_predictor_and_checkpoint_roundtrip(tmp_path):
+    """Checkpoint dict of trainer.py:209-224 -> Predictor.from_checkpoint (predictor.py:61-137) -> strings."""
+    from img2latex_amd.training import Predictor, TokenTable, TrainStep, save_checkpoint
+    d, cfg, sd_kw = load("tiny_l2_attn")
+    m, _ = model_for("tiny_l2_attn")
+    vocab = {"<PAD>": 0, "<START>": 1, "<END>": 2, "<UNK>": 3}
+    vocab.update({f"t{i}": i for i in range(4, cfg["vocab_size"])})
+    tok = TokenTable(vocab, max_sequence_length=150)
+    config = {"model": {"name": "cnn_lstm", "embedding_dim": cfg["embedding_dim"],
+                        "encoder": {"cnn": {k: v for k, v in synth.encoder_params(cfg).items() if k != "embedding_dim"}},
+                        "decoder": synth.decoder_params(cfg)}}
+    path = str(tmp_path / "best_checkpoint.pt")
+    save_checkpoint(path, m, tok, config, epoch=3, step=77)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) >= {"epoch", "step", "model_state_dict", "optimizer_state_dict", "metrics", "config", "tokenizer_config"}
+    pred = Predictor.from_checkpoint(path, device=torch.device(DEV))
+    x = images(cfg, device=DEV)
+    rows = pred.predict_batch_ids(x, max_length=32)
+    assert [r[1:] for r in rows] == padded_to_lists(d["g5_ids"], d["g5_len"])          # fixture G5 (START stripped)
+    texts = pred.predict_batch([x[i] for i in range(4)], max_length=32, batch_size=3)
+    assert texts == [" ".join(f"t{t}" for t in r[1:] if t > 3) for r in rows]
+    one = pred.predict(x[1], max_length=32)
+    assert one == " ".join(f"t{t}" for t in d["g3_b1_ids"] if t > 3)
+    with pytest.raises(TypeError):
+        pred.predict_batch(["formula.png"])
+    # optimizer state in torch.optim.Adam's layout, loadable by the real optimizer
+    m2, _ = model_for("tiny_l1")
+    ts = TrainStep(m2)
+    forms = torch.from_numpy(synth.make_formulas(4, 10, 50, seed=1, min_len=4)).to(DEV)
+    ts.step(images(load("tiny_l1")[1], device=DEV), forms)
+    osd = ts.optimizer_state_dict()
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt.load_state_dict(osd)
+    assert opt.state_dict()["state"][0]["exp_avg"].shape == m2.encoder.cnn_layers[0].weight.shape
+    m2.eval()
+    del _MODELS[("tiny_l1", repr(None))]            # its parameters were updated by the step above
