@@ -25,7 +25,8 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsign
 
 // ------------------------------------------------------------------ bf16 GEMM with fused epilogue
 // out[m][n] = act( acc[m][n] * scale[n] + bias[n] + res[m][n] ),  acc = sum_k A[m][k] * W[n][k]
-constexpr int GM = 128, GN = 128, GK = 32, GLD = 40;      // LDS row stride 40 bf16 = 80 B: conflict-free b128 reads
+constexpr int GM = 128, GK = 64, GLD = 72;      // LDS row stride 72 bf16 = 144 B: conflict-free b128 reads
+constexpr int GNL = GM * GK / 8 / 256;                     // 16-byte loads per thread per operand tile
 
 struct BfGemm {
     const bf16_t* A; long lda;
@@ -36,7 +37,10 @@ struct BfGemm {
     int M, N, K, relu;
 };
 
+template <int NTW>      // 32-column MFMA tiles per wave: workgroup tile = 128 x (64*NTW)
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(BfGemm g) {
+    constexpr int GN = 64 * NTW;
+    constexpr int GNLW = GN * GK / 8 / 256;
     __shared__ __attribute__((aligned(16))) bf16_t As[GM * GLD];
     __shared__ __attribute__((aligned(16))) bf16_t Ws[GN * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,48 +48,70 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(BfGemm g) {
     const int li = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.x * GN, m0 = blockIdx.y * GM;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NTW];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NTW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    uint4 ra[GNL], rw[GNLW];
+    auto fetch = [&](int k0) {                             // global -> registers
+#pragma unroll
+        for (int i = 0; i < GNL; ++i) {
+            const int idx = tid + i * 256;                 // 128 rows x (GK/8) chunks of 8 bf16
+            const int row = idx / (GK / 8), c8 = (idx % (GK / 8)) * 8;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (k0 + c8 < g.K && m0 + row < g.M)           // K % 8 == 0
+                ra[i] = *reinterpret_cast<const uint4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + c8);
+        }
+#pragma unroll
+        for (int i = 0; i < GNLW; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (GK / 8), c8 = (idx % (GK / 8)) * 8;
+            rw[i] = make_uint4(0, 0, 0, 0);
+            if (k0 + c8 < g.K && n0 + row < g.N)
+                rw[i] = *reinterpret_cast<const uint4*>(g.W + (size_t)(n0 + row) * g.ldw + k0 + c8);
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < g.K; k0 += GK) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 256;                 // 128 rows x 4 chunks of 8 bf16
-            const int row = idx >> 2, c8 = (idx & 3) * 8;
-            uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
-            if (k0 + c8 < g.K) {                           // K % 8 == 0
-                if (m0 + row < g.M) va = *reinterpret_cast<const uint4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + c8);
-                if (n0 + row < g.N) vw = *reinterpret_cast<const uint4*>(g.W + (size_t)(n0 + row) * g.ldw + k0 + c8);
-            }
-            *reinterpret_cast<uint4*>(&As[row * GLD + c8]) = va;
-            *reinterpret_cast<uint4*>(&Ws[row * GLD + c8]) = vw;
+        for (int i = 0; i < GNL; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (GK / 8), c8 = (idx % (GK / 8)) * 8;
+            *reinterpret_cast<uint4*>(&As[row * GLD + c8]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < GNLW; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (GK / 8), c8 = (idx % (GK / 8)) * 8;
+            *reinterpret_cast<uint4*>(&Ws[row * GLD + c8]) = rw[i];
         }
         __syncthreads();
+        if (k0 + GK < g.K) fetch(k0 + GK);                 // next tile in flight during the MFMAs
 #pragma unroll
         for (int ks = 0; ks < GK; ks += 16) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[2], b[NTW];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t)
                 a[t] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + t * 32 + li) * GLD + ks + 8 * lh]);
-                b[t] = *reinterpret_cast<const bf16x8*>(&Ws[(wn * 64 + t * 32 + li) * GLD + ks + 8 * lh]);
-            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                b[t] = *reinterpret_cast<const bf16x8*>(&Ws[(wn * 32 * NTW + t * 32 + li) * GLD + ks + 8 * lh]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         }
         __syncthreads();
     }
     // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 64 + nt * 32 + li;
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = n0 + wn * 32 * NTW + nt * 32 + li;
         if (n >= g.N) continue;
         const float sc = g.scale ? g.scale[n] : 1.f, bi = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
@@ -146,6 +172,40 @@ __global__ __launch_bounds__(256) void im2col_nchw_f32_kernel(const float* __res
             if (yi >= 0 && yi < H && xi >= 0 && xi < W) v = x[(((size_t)b * Cin + ci) * H + yi) * W + xi];
         }
         col[i] = f2bf(v);
+    }
+}
+
+// Stem im2col (kh x kw up to 7x7, Cin <= 4, stride 2) with the input window staged in LDS: a workgroup builds
+// 32 consecutive output columns of one output row; global reads run along image rows (coalesced).
+constexpr int STEM_TW = 32;
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int B,
+                                                          int Cin, int H, int W, int Ho, int Wo, int kh, int kw,
+                                                          int stride, int pad, int Kp) {
+    extern __shared__ float win[];                         // [Cin][kh][wcols]
+    const int wcols = (STEM_TW - 1) * stride + kw;
+    const int xo0 = blockIdx.x * STEM_TW, yo = blockIdx.y, b = blockIdx.z;
+    const int xi0 = xo0 * stride - pad, yi0 = yo * stride - pad;
+    const int n = Cin * kh * wcols;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / (kh * wcols);
+        const int rem = i - c * (kh * wcols);
+        const int r = rem / wcols, cc = rem - r * wcols;
+        const int yi = yi0 + r, xi = xi0 + cc;
+        win[i] = (yi >= 0 && yi < H && xi >= 0 && xi < W) ? x[(((size_t)b * Cin + c) * H + yi) * W + xi] : 0.f;
+    }
+    __syncthreads();
+    const int K = kh * kw * Cin;
+    for (int i = threadIdx.x; i < STEM_TW * Kp; i += 256) {
+        const int p = i / Kp, k = i - p * Kp;
+        const int xo = xo0 + p;
+        if (xo >= Wo) continue;
+        float v = 0.f;
+        if (k < K) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int ky = tap / kw, kx = tap - ky * kw;
+            v = win[(ci * kh + ky) * wcols + p * stride + kx];
+        }
+        col[(((size_t)b * Ho + yo) * Wo + xo) * Kp + k] = f2bf(v);
     }
 }
 
@@ -266,7 +326,11 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     if (direct) {
         g.A = static_cast<const bf16_t*>(x); g.lda = Cin;
     } else {
-        if (x_is_nchw_f32)
+        const size_t stem_lds = (size_t)Cin * kh * ((STEM_TW - 1) * stride + kw) * sizeof(float);
+        if (x_is_nchw_f32 && stem_lds <= 48 * 1024 && Ho <= 65535 && B <= 65535)
+            hipLaunchKernelGGL(im2col_stem_kernel, dim3(i2l_cdiv(Wo, STEM_TW), Ho, B), dim3(256), stem_lds, s,
+                               static_cast<const float*>(x), col, B, Cin, H, W, Ho, Wo, kh, kw, stride, pad, Kp);
+        else if (x_is_nchw_f32)
             hipLaunchKernelGGL(im2col_nchw_f32_kernel, dim3(grid_for(M * Kp)), dim3(256), 0, s,
                                static_cast<const float*>(x), col, B, Cin, H, W, Ho, Wo, kh, kw, stride, pad, Kp);
         else
@@ -280,9 +344,11 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     g.res = static_cast<const bf16_t*>(residual); g.ldr = Cout;
     g.C = static_cast<bf16_t*>(y); g.ldc = Cout;
     g.M = (int)M; g.N = Cout; g.K = Kp; g.relu = relu;
-    dim3 grid(i2l_cdiv(Cout, GN), i2l_cdiv((int)M, GM));
+    const int gn = Cout <= 64 ? 64 : 128;                  // narrow tile for the 64-channel layers (no wasted MFMAs)
+    dim3 grid(i2l_cdiv(Cout, gn), i2l_cdiv((int)M, GM));
     if (grid.y > 65535) return I2L_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, s, g);
+    if (gn == 64) hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<2>, grid, dim3(256), 0, s, g);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }
