@@ -24,7 +24,8 @@ namespace {
 
 constexpr int MAXL = I2L_MAX_LSTM_LAYERS;
 constexpr int NT = 256;
-constexpr int PF = 16;
+constexpr int PF = 8;
+constexpr int RES_KR = 96, RES_KL = 32;     // rows of W_hh kept in registers / LDS by the recurrence fast paths
 
 // ------------------------------------------------------------------ dropout mask
 __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned stream, unsigned long long idx,
@@ -94,7 +95,7 @@ __device__ __forceinline__ void fma_rows(float4 (&acc)[R], const float4 (&w)[PF]
     }
 }
 
-// acc[r] += sum_{k<count} W[k][0..3] * xs[r*xstride + k];  count % 32 == 0.
+// acc[r] += sum_{k<count} W[k][0..3] * xs[r*xstride + k];  count % (2*PF) == 0.
 template <int R>
 __device__ __forceinline__ void matvec(float4 (&acc)[R], const float* __restrict__ Wcol, size_t ldw, const float* xs,
                                        int xstride, int count) {
@@ -121,6 +122,41 @@ __device__ __forceinline__ void matvec(float4 (&acc)[R], const float* __restrict
     fma_rows<R>(acc, wb, xs, xstride, k + PF);
 }
 
+// One-row matvec whose first KR weight rows sit in this thread's registers and the next KL rows in LDS for the
+// whole kernel (loaded once); only the remaining rows are streamed from L2 each step.  Same k order as matvec.
+template <int KR, int KL>
+__device__ __forceinline__ void matvec_res(float4& acc, const float4 (&wres)[KR > 0 ? KR : 1], const float* wl, int ldl,
+                                           const float* __restrict__ Wcol, size_t ldw, const float* xs, int count) {
+#pragma unroll
+    for (int k4 = 0; k4 < KR; k4 += 4) {
+        const float4 xa = *reinterpret_cast<const float4*>(xs + k4);
+        const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc.x = fmaf(wres[k4 + i].x, xv[i], acc.x);
+            acc.y = fmaf(wres[k4 + i].y, xv[i], acc.y);
+            acc.z = fmaf(wres[k4 + i].z, xv[i], acc.z);
+            acc.w = fmaf(wres[k4 + i].w, xv[i], acc.w);
+        }
+    }
+#pragma unroll 2
+    for (int k4 = 0; k4 < KL; k4 += 4) {
+        const float4 xa = *reinterpret_cast<const float4*>(xs + KR + k4);
+        const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 wv = *reinterpret_cast<const float4*>(wl + (size_t)(k4 + i) * ldl);
+            acc.x = fmaf(wv.x, xv[i], acc.x);
+            acc.y = fmaf(wv.y, xv[i], acc.y);
+            acc.z = fmaf(wv.z, xv[i], acc.z);
+            acc.w = fmaf(wv.w, xv[i], acc.w);
+        }
+    }
+    float4 a1[1] = {acc};
+    matvec<1>(a1, Wcol + (size_t)(KR + KL) * ldw, ldw, xs + KR + KL, 0, count - KR - KL);
+    acc = a1[0];
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------ saved tensors
@@ -139,7 +175,8 @@ struct TrainBuf {
 };
 
 // Forward recurrence: workgroup = R batch rows, all T steps, all layers (no inter-workgroup traffic).
-template <int R>
+// KR / KL > 0: fast path for R == 1, L == 1, H == NT (thread = hidden unit): part of W_hh stays on chip.
+template <int R, int KR, int KL>
 __global__ __launch_bounds__(NT) void lstm_train_fwd_kernel(TrainBuf p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, L = p.L, B = p.B, T = p.T;
@@ -147,14 +184,46 @@ __global__ __launch_bounds__(NT) void lstm_train_fwd_kernel(TrainBuf p) {
     float* hs = smem;                    // [2][L][R][H]  raw h (recurrence)
     float* hd = hs + 2 * L * R * H;      // [L][R][H]     inter-layer-dropped h of the current step
     float* cs = hd + L * R * H;          // [L][R][H]
+    float* wl = cs + L * R * H;          // [KL][4H] resident rows of WhhT[0]
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * R;
     const float inv_keep = p.p > 0.f ? 1.f / (1.f - p.p) : 1.f;
     for (int idx = tid; idx < 2 * L * R * H; idx += NT) hs[idx] = 0.f;
     for (int idx = tid; idx < L * R * H; idx += NT) { cs[idx] = 0.f; hd[idx] = 0.f; }
+    float4 wres[KR > 0 ? KR : 1];
+    if (KR > 0) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) wres[k] = *reinterpret_cast<const float4*>(p.WhhT[0] + (size_t)k * G + 4 * tid);
+    }
+    if (KL > 0) {
+        const float4* src = reinterpret_cast<const float4*>(p.WhhT[0] + (size_t)KR * G);
+        for (int idx = tid; idx < KL * H; idx += NT) reinterpret_cast<float4*>(wl)[idx] = src[idx];
+    }
     __syncthreads();
     int par = 0;
     for (int t = 0; t < T; ++t) {
+        if (KR + KL > 0) {                       // R == 1, L == 1, H == NT
+            const float* h_old = hs + (size_t)par * H;
+            float* h_new = hs + (size_t)(par ^ 1) * H;
+            const int row = row0;
+            const size_t bt = (size_t)row * T + t;
+            float4 acc = *reinterpret_cast<const float4*>(p.GX + bt * G + 4 * tid);
+            matvec_res<KR, KL>(acc, wres, wl + 4 * tid, (int)G, p.WhhT[0] + 4 * tid, G, h_old, H);
+            const float ig = sigmoidf_(acc.x), fg = sigmoidf_(acc.y);
+            const float gg = tanhf(acc.z), og = sigmoidf_(acc.w);
+            const float cn = fg * cs[tid] + ig * gg;
+            const float hn = og * tanhf(cn);
+            cs[tid] = cn;
+            h_new[tid] = hn;
+            *reinterpret_cast<float4*>(p.ACT[0] + bt * G + 4 * tid) = make_float4(ig, fg, gg, og);
+            p.C[0][bt * H + tid] = cn;
+            p.Hout[0][bt * H + tid] = hn;
+            if (t == 0) p.Hprev[0][bt * H + tid] = 0.f;
+            if (t + 1 < T) p.Hprev[0][(bt + 1) * H + tid] = hn;
+            __syncthreads();
+            par ^= 1;
+            continue;
+        }
         for (int l = 0; l < L; ++l) {
             const float* h_old = hs + ((size_t)par * L + l) * R * H;
             float* h_new = hs + ((size_t)(par ^ 1) * L + l) * R * H;
@@ -216,7 +285,7 @@ struct BwdBuf {
     unsigned long long seed;
 };
 
-template <int R>
+template <int R, int KR, int KL>
 __global__ __launch_bounds__(NT) void lstm_train_bwd_kernel(BwdBuf p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, L = p.L, B = p.B, T = p.T;
@@ -230,12 +299,30 @@ __global__ __launch_bounds__(NT) void lstm_train_bwd_kernel(BwdBuf p) {
     float* dh_low = dc_next + L * R * H;     // [R][H]     gradient handed to the layer below
     float* dgs = dh_low + R * H;             // [R][4H]    gate gradients of the current (layer, step)
     float* part = dgs + R * G;               // [NG][R][H] partial sums of the row-group split
+    float* wl = part + (size_t)NG * R * H;   // [NG][KL][H] resident rows of W_hh[0] (fast path)
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * R;
     const float inv_keep = p.p > 0.f ? 1.f / (1.f - p.p) : 1.f;
     for (int idx = tid; idx < 2 * L * R * H; idx += NT) dh_rec[idx] = 0.f;   // dh_rec and dc_next are adjacent
     __syncthreads();
     const int cg = tid % CG, ng = tid / CG;
+    // fast path (R == 1, L == 1, H == NT: CG = 64, NG = 4): thread (cg, ng) keeps the first KR rows of its row
+    // group of W_hh in registers, the next KL rows of every group sit in LDS
+    float4 wres[KR > 0 ? KR : 1];
+    if (KR > 0) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+            wres[k] = *reinterpret_cast<const float4*>(p.Whh[0] + ((size_t)ng * rows_per + k) * H + 4 * cg);
+    }
+    if (KL > 0) {
+        for (int idx = tid; idx < NG * KL * (H / 4); idx += NT) {
+            const int g2 = idx / (KL * (H / 4)), rem = idx - g2 * (KL * (H / 4));
+            const int k = rem / (H / 4), c4 = rem - k * (H / 4);
+            reinterpret_cast<float4*>(wl)[idx] =
+                *reinterpret_cast<const float4*>(p.Whh[0] + ((size_t)g2 * rows_per + KR + k) * H + 4 * c4);
+        }
+        __syncthreads();
+    }
     for (int t = T - 1; t >= 0; --t) {
         for (int l = L - 1; l >= 0; --l) {
             for (int j = tid; j < H; j += NT) {
@@ -273,7 +360,11 @@ __global__ __launch_bounds__(NT) void lstm_train_bwd_kernel(BwdBuf p) {
                     float4 acc[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    matvec<R>(acc, W + (size_t)ng * rows_per * H + 4 * cg, (size_t)H, dgs + ng * rows_per, (int)G, rows_per);
+                    if (KR + KL > 0)
+                        matvec_res<KR, KL>(acc[0], wres, wl + ((size_t)ng * KL) * H + 4 * cg, H,
+                                           W + (size_t)ng * rows_per * H + 4 * cg, (size_t)H, dgs + ng * rows_per, rows_per);
+                    else
+                        matvec<R>(acc, W + (size_t)ng * rows_per * H + 4 * cg, (size_t)H, dgs + ng * rows_per, (int)G, rows_per);
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         *reinterpret_cast<float4*>(part + ((size_t)ng * R + r) * H + 4 * cg) = acc[r];
@@ -564,9 +655,21 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
         const size_t lds = R * per_row;
         if (lds > 64 * 1024) return I2L_ERR_UNSUPPORTED;
         dim3 grid(i2l_cdiv(B, R));
-        if (R == 1) hipLaunchKernelGGL(lstm_train_fwd_kernel<1>, grid, dim3(NT), lds, s, p);
-        else if (R == 2) hipLaunchKernelGGL(lstm_train_fwd_kernel<2>, grid, dim3(NT), lds, s, p);
-        else hipLaunchKernelGGL(lstm_train_fwd_kernel<4>, grid, dim3(NT), lds, s, p);
+        bool done = false;
+        if (R == 1 && L == 1 && H == NT && T >= 8) {        // part of W_hh resident on chip
+            const size_t lds_r = lds + (size_t)RES_KL * G * sizeof(float);
+            auto kern = lstm_train_fwd_kernel<1, RES_KR, RES_KL>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_r) == hipSuccess) {
+                hipLaunchKernelGGL(kern, grid, dim3(NT), lds_r, s, p);
+                done = true;
+            }
+        }
+        if (!done) {
+            if (R == 1) hipLaunchKernelGGL((lstm_train_fwd_kernel<1, 0, 0>), grid, dim3(NT), lds, s, p);
+            else if (R == 2) hipLaunchKernelGGL((lstm_train_fwd_kernel<2, 0, 0>), grid, dim3(NT), lds, s, p);
+            else hipLaunchKernelGGL((lstm_train_fwd_kernel<4, 0, 0>), grid, dim3(NT), lds, s, p);
+        }
         I2L_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(dropout_rows_kernel, dim3(grid_for(BT * H)), dim3(256), 0, s, (const float*)F(lo.Hout[L - 1]),
@@ -665,9 +768,21 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         const size_t lds = R * per_row;
         if (lds > 64 * 1024) return I2L_ERR_UNSUPPORTED;
         dim3 grid(i2l_cdiv(B, R));
-        if (R == 1) hipLaunchKernelGGL(lstm_train_bwd_kernel<1>, grid, dim3(NT), lds, s, p);
-        else if (R == 2) hipLaunchKernelGGL(lstm_train_bwd_kernel<2>, grid, dim3(NT), lds, s, p);
-        else hipLaunchKernelGGL(lstm_train_bwd_kernel<4>, grid, dim3(NT), lds, s, p);
+        bool done = false;
+        if (R == 1 && L == 1 && H == NT && T >= 8) {
+            const size_t lds_r = lds + (size_t)NG * RES_KL * H * sizeof(float);
+            auto kern = lstm_train_bwd_kernel<1, RES_KR, RES_KL>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_r) == hipSuccess) {
+                hipLaunchKernelGGL(kern, grid, dim3(NT), lds_r, s, p);
+                done = true;
+            }
+        }
+        if (!done) {
+            if (R == 1) hipLaunchKernelGGL((lstm_train_bwd_kernel<1, 0, 0>), grid, dim3(NT), lds, s, p);
+            else if (R == 2) hipLaunchKernelGGL((lstm_train_bwd_kernel<2, 0, 0>), grid, dim3(NT), lds, s, p);
+            else hipLaunchKernelGGL((lstm_train_bwd_kernel<4, 0, 0>), grid, dim3(NT), lds, s, p);
+        }
         I2L_CHECK_LAUNCH();
     }
     // weight gradients: one GEMM each over all B*T rows
