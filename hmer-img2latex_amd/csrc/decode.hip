@@ -108,6 +108,7 @@ struct DecodeParams {
     float* logits;
     float temperature;
     int use_temp, select, stop, end_id;
+    int top_k; float top_p; unsigned long long seed; float* probs;   // I2L_SELECT_SAMPLE only
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -346,11 +347,41 @@ __device__ __forceinline__ void block_argmax(float (&best)[R], int (&besti)[R], 
     __syncthreads();
 }
 
+// workgroup-wide sum / max (every thread gets the result); red: LDS [NT/64]; contain two __syncthreads()
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NT / 64; ++wv) s += red[wv];
+    __syncthreads();
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red, int tid) {
+    v = wave_max(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = red[0];
+#pragma unroll
+    for (int wv = 1; wv < NT / 64; ++wv) s = fmaxf(s, red[wv]);
+    __syncthreads();
+    return s;
+}
+// counter-based uniform in [0,1): splitmix64 finaliser of (seed, row, step); 24 random bits
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned row, unsigned step) {
+    unsigned long long z = seed + ((unsigned long long)row << 32 | step) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 // KR / KL > 0 (fast path for R == 1, L == 1, H <= 256: thread j owns hidden unit j for the whole loop):
 // rows [0,KR) of WhhT stay in the thread's registers and rows [KR,KR+KL) in LDS for all steps, so only
 // H-KR-KL rows are streamed from L2 per step.  The fmaf chain still runs k = 0..H-1 in order, so the
 // results are bit-identical to the streaming-only kernel.
-template <int R, int KR, int KL>
+template <int R, int KR, int KL, bool SAMPLE = false>
 __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const StepWeights& w = p.w;
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
     int* fin_s = tok_s + R;                    // [R]
     float* psum = reinterpret_cast<float*>(fin_s + R + ((4 - ((10 * R) & 3)) & 3));   // [R][128][4], 16-byte aligned
     float* wl = psum + R * 512;                         // [KL][4H] resident rows of WhhT[0]
-    float* lg = wl + (size_t)KL * 4 * H;                // [R][Vp], only with I2L_SELECT_SOFTMAX
+    float* lg = wl + (size_t)KL * 4 * H;                // [R][Vp], only with I2L_SELECT_SOFTMAX / _SAMPLE
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * R;
@@ -467,10 +498,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
         float best[R];
         int besti[R];
         if (KR + KL > 0)
-            project<R, true>(w, h_top, lp, p.select == I2L_SELECT_SOFTMAX ? lg : nullptr, p.use_temp != 0,
+            project<R, true>(w, h_top, lp, p.select != I2L_SELECT_LOGITS ? lg : nullptr, p.use_temp != 0,
                              p.temperature, best, besti, psum, tid, &pre);
         else
-            project<R>(w, h_top, lp, p.select == I2L_SELECT_SOFTMAX ? lg : nullptr, p.use_temp != 0, p.temperature,
+            project<R>(w, h_top, lp, p.select != I2L_SELECT_LOGITS ? lg : nullptr, p.use_temp != 0, p.temperature,
                        best, besti, psum, tid);
         block_argmax<R>(best, besti, redv, redi, tid);
         if (p.select == I2L_SELECT_SOFTMAX) {
@@ -500,6 +531,85 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
             block_argmax<R>(pbest, pbesti, redv, redi, tid);
 #pragma unroll
             for (int r = 0; r < R; ++r) besti[r] = pbesti[r];
+        }
+        if (SAMPLE) {
+            // predictor.py:295-331: probs = softmax(logits / T); top-k mask (keep p >= k-th largest); top-p mask
+            // (drop a token once the probability mass sorted before it exceeds top_p); renormalise; one multinomial
+            // draw by inverse CDF with a counter-based uniform of (seed, row, step).
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float* pr = lg + (size_t)r * w.Vp;
+                float sm = 0.f;
+                for (int v = tid; v < V; v += NT) sm += expf(pr[v] - best[r]);
+                sm = block_sum(sm, redv, tid);
+                for (int v = tid; v < V; v += NT) pr[v] = expf(pr[v] - best[r]) / sm;
+                __syncthreads();
+                if (p.top_k > 0) {
+                    const int kk = min(p.top_k, V);
+                    float kth = -1.f;
+                    for (int v = tid; v < V; v += NT) {
+                        const float pv = pr[v];
+                        int gt = 0, ge = 0;
+                        for (int u = 0; u < V; ++u) { const float pu = pr[u]; gt += pu > pv; ge += pu >= pv; }
+                        if (gt < kk && kk <= ge) kth = pv;
+                    }
+                    kth = block_max(kth, redv, tid);
+                    float s2 = 0.f;
+                    for (int v = tid; v < V; v += NT) { const float q = pr[v] < kth ? 0.f : pr[v]; pr[v] = q; s2 += q; }
+                    s2 = block_sum(s2, redv, tid);
+                    if (s2 > 0.f) for (int v = tid; v < V; v += NT) pr[v] = pr[v] / s2;
+                    __syncthreads();
+                }
+                if (p.top_p > 0.f) {
+                    float* nx = lg + (size_t)(R + r) * w.Vp;         // second buffer: masked values
+                    float s2 = 0.f;
+                    for (int v = tid; v < V; v += NT) {
+                        const float pv = pr[v];
+                        float before = 0.f;                          // mass sorted ahead of v (descending, index breaks ties)
+                        for (int u = 0; u < V; ++u) { const float pu = pr[u]; if (pu > pv || (pu == pv && u < v)) before += pu; }
+                        const float q = before > p.top_p ? 0.f : pv;
+                        nx[v] = q;
+                        s2 += q;
+                    }
+                    __syncthreads();
+                    for (int v = tid; v < V; v += NT) pr[v] = nx[v];
+                    s2 = block_sum(s2, redv, tid);
+                    if (s2 > 0.f) for (int v = tid; v < V; v += NT) pr[v] = pr[v] / s2;
+                    __syncthreads();
+                }
+                if (p.probs && row0 + r < B) {
+                    float* po = p.probs + ((size_t)(row0 + r) * T + t) * V;
+                    for (int v = tid; v < V; v += NT) po[v] = pr[v];
+                }
+                // inverse CDF: thread t owns the contiguous chunk [t*CH, (t+1)*CH)
+                const int CH = (V + NT - 1) / NT;
+                float part = 0.f;
+                for (int v = tid * CH; v < min(V, (tid + 1) * CH); ++v) part += pr[v];
+                float* scan = psum;                                  // [NT] scratch (psum is free here)
+                scan[tid] = part;
+                __syncthreads();
+                if (tid == 0) {
+                    float run = 0.f;
+                    for (int i = 0; i < NT; ++i) { const float x = scan[i]; scan[i] = run; run += x; }
+                    scan[NT] = run;
+                }
+                __syncthreads();
+                const float total = scan[NT];
+                const float target = uniform01(p.seed, (unsigned)(row0 + r), (unsigned)t) * total;
+                int pick = 0x7fffffff;
+                float run = scan[tid];
+                for (int v = tid * CH; v < min(V, (tid + 1) * CH); ++v) {
+                    const float q = pr[v];
+                    if (q > 0.f && run + q > target && pick == 0x7fffffff && run <= target) pick = v;
+                    run += q;
+                }
+                float dummy = pick == 0x7fffffff ? -1.f : 1.f;
+                int pk = pick;
+                float bv[1] = {dummy};
+                int bi[1] = {pk};
+                block_argmax<1>(bv, bi, redv, redi, tid);            // the (unique) thread that found the crossing wins
+                besti[r] = bi[0] < V ? bi[0] : besti[r];             // rounding corner: fall back to the arg max
+            }
         }
         if (tid == 0) {
 #pragma unroll
@@ -763,7 +873,8 @@ constexpr int RES_KR = 76, RES_KL = 36;   // resident rows of WhhT[0]: registers
 
 size_t decode_lds_bytes(int R, int L, int H, int Vp, int select, int KL = 0) {
     size_t floats = (size_t)3 * L * R * H + 4 * R + 4 * R + R + R + 4 + (size_t)R * 512 + (size_t)KL * 4 * H;
-    if (select == I2L_SELECT_SOFTMAX) floats += (size_t)R * Vp;
+    if (select != I2L_SELECT_LOGITS) floats += (size_t)R * Vp;
+    if (select == I2L_SELECT_SAMPLE) floats += (size_t)R * Vp;
     return floats * sizeof(float);
 }
 
@@ -830,15 +941,41 @@ extern "C" int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* en
     return I2L_OK;
 }
 
+namespace {
+int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
+                  const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
+                  int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream);
+}
+
 extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
                                  const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
                                  float temperature, int select, int stop, int end_id, int32_t* ids_out,
                                  float* logits_out, float* h_out, float* c_out, i2l_stream_t stream) {
+    if (select != I2L_SELECT_LOGITS && select != I2L_SELECT_SOFTMAX) return I2L_ERR_ARG;
+    return launch_decode(w, workspace, rows, steps, tok0, forced, h0, c0, temperature, select, stop, end_id, 0, 0.f, 0ull,
+                         ids_out, logits_out, nullptr, h_out, c_out, stream);
+}
+
+extern "C" int i2l_sample_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
+                                 const int32_t* tok0, const float* h0, const float* c0, float temperature, int top_k,
+                                 float top_p, uint64_t seed, int stop, int end_id, int32_t* ids_out, float* probs_out,
+                                 float* h_out, float* c_out, i2l_stream_t stream) {
+    if (!(temperature > 0.f) || top_k < 0 || top_p < 0.f || (top_k == 0 && top_p == 0.f)) return I2L_ERR_ARG;
+    if (w && w->vocab > 8 * 256) return I2L_ERR_UNSUPPORTED;
+    return launch_decode(w, workspace, rows, steps, tok0, nullptr, h0, c0, temperature, I2L_SELECT_SAMPLE, stop, end_id,
+                         top_k, top_p, (unsigned long long)seed, ids_out, nullptr, probs_out, h_out, c_out, stream);
+}
+
+namespace {
+int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
+                  const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
+                  int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream) {
     int rc = check_weights(w);
     if (rc != I2L_OK) return rc;
     if (!workspace || !tok0 || rows <= 0 || steps <= 0) return I2L_ERR_ARG;
     if ((h0 == nullptr) != (c0 == nullptr)) return I2L_ERR_ARG;
-    if (select != I2L_SELECT_LOGITS && select != I2L_SELECT_SOFTMAX) return I2L_ERR_ARG;
     if (stop != I2L_STOP_NONE && stop != I2L_STOP_STICKY) return I2L_ERR_ARG;
     const int V = w->vocab, E = w->embed, H = w->hidden, L = w->layers;
     const Layout lo = make_layout(rows, V, E, H, L);
@@ -851,6 +988,7 @@ extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* works
     p.h_out = h_out; p.c_out = c_out; p.ids = ids_out; p.logits = logits_out;
     p.temperature = temperature; p.use_temp = (temperature != 1.0f) ? 1 : 0;
     p.select = select; p.stop = stop; p.end_id = end_id;
+    p.top_k = top_k; p.top_p = top_p; p.seed = seed; p.probs = probs_out;
 
     // rows per workgroup: fill the 256 CUs first, then stack rows (weights are streamed once per workgroup per step)
     int R = rows <= 256 ? 1 : (rows <= 512 ? 2 : 4);
@@ -860,6 +998,13 @@ extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* works
     const dim3 grid(i2l_cdiv(rows, R));
     hipStream_t s = i2l_s(stream);
     // fast path: weights partly resident on chip; pays a one-off fill, so only for real loops
+    if (select == I2L_SELECT_SAMPLE) {
+        if (R == 1) hipLaunchKernelGGL((decode_kernel<1, 0, 0, true>), grid, dim3(NT), lds, s, p);
+        else if (R == 2) hipLaunchKernelGGL((decode_kernel<2, 0, 0, true>), grid, dim3(NT), lds, s, p);
+        else hipLaunchKernelGGL((decode_kernel<4, 0, 0, true>), grid, dim3(NT), lds, s, p);
+        I2L_CHECK_LAUNCH();
+        return I2L_OK;
+    }
     const bool resident = R == 1 && L == 1 && H == 256 && steps >= 8;
     if (resident) {
         const size_t lds_r = decode_lds_bytes(1, 1, H, lo.Vp, select, RES_KL);
@@ -878,6 +1023,7 @@ extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* works
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }
+}  // namespace
 
 namespace {
 

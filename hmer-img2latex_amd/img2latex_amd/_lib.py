@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libimg2latex_hip.so")
 
 OK = 0
 STOP_NONE, STOP_STICKY = 0, 1
-SELECT_LOGITS, SELECT_SOFTMAX = 0, 1
+SELECT_LOGITS, SELECT_SOFTMAX, SELECT_SAMPLE = 0, 1, 2
 PREP_WEIGHTS, PREP_ROWS, PREP_ALL = 1, 2, 3
 MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
 
@@ -59,6 +59,9 @@ _SIGNATURES = {
     "i2l_decoder_prepare": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "i2l_greedy_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    "i2l_sample_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                                  c_int, c_float, c_uint64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
     "i2l_beam_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "i2l_beam_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,

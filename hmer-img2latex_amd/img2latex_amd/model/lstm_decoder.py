@@ -163,6 +163,25 @@ class LSTMDecoder(nn.Module):
         del keep
         return ids, logits, ((h, c) if want_state else None)
 
+    def sample_steps(self, encoder_output: torch.Tensor, steps: int, tok0: torch.Tensor, temperature: float,
+                     top_k: int, top_p: float, seed: int, stop: int = _lib.STOP_STICKY, end_id: int = -1,
+                     hidden: Optional[Hidden] = None, want_probs: bool = False):
+        """prepare + one i2l_sample_decode launch (predictor.py:295-331).  Returns (ids, probs or None)."""
+        w, keep, enc = self.prepare(encoder_output)
+        rows, dev = enc.shape[0], enc.device
+        tok0 = _lib.require_gpu(tok0, "tok0", torch.int32)
+        h0 = c0 = None
+        if hidden is not None:
+            h0, c0 = _lib.require_gpu(hidden[0], "h0"), _lib.require_gpu(hidden[1], "c0")
+        ids = torch.empty((rows, steps), dtype=torch.int32, device=dev)
+        probs = torch.empty((rows, steps, self.vocab_size), dtype=torch.float32, device=dev) if want_probs else None
+        _lib.check(_lib.lib().i2l_sample_decode(
+            ctypes.byref(w), self._ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(h0), _lib.ptr(c0),
+            float(temperature), int(top_k), float(top_p), int(seed) & 0xFFFFFFFFFFFFFFFF, stop, int(end_id),
+            ids.data_ptr(), _lib.ptr(probs), None, None, _lib.stream_ptr()), "sample_decode")
+        del keep
+        return ids, probs
+
     # ------------------------------------------------------------------ reference surface
     def forward(self, encoder_output: torch.Tensor, target_sequence: torch.Tensor, hidden=None) -> torch.Tensor:
         """Teacher forcing (decoder.py:100-195): (B,E), (B,T) int64 -> logits (B,T,V).

@@ -103,13 +103,24 @@ class Predictor:
             t = torch.stack(items)
         return t.to(self.device, dtype=torch.float32).contiguous()
 
-    def predict_batch_ids(self, images, max_length: int = 141, temperature: float = 1.0) -> List[List[int]]:
-        """Token ids of the batched greedy loop (predictor.py:254-361): START kept, cut before the first END."""
+    def predict_batch_ids(self, images, max_length: int = 141, temperature: float = 1.0, top_k: int = 0,
+                          top_p: float = 0.0, seed: Optional[int] = None) -> List[List[int]]:
+        """Token ids of the batched loop (predictor.py:254-361): START kept, cut before the first END.
+        Sampling (multinomial over the top-k / top-p masked softmax) iff temperature > 0 and
+        (top_k > 0 or top_p > 0), exactly the reference's condition (:330); argmax of softmax otherwise."""
         x = self._as_batch(images)
+        start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
         with torch.no_grad():
             enc = self.model.encoder(x)
-            ids, _ = self.model.greedy_ids(enc, self.tokenizer.start_token_id, self.tokenizer.end_token_id, max_length,
-                                           temperature, stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX)
+            if temperature > 0 and (top_k > 0 or top_p > 0.0):
+                if seed is None:
+                    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                tok0 = torch.full((enc.shape[0],), int(start), dtype=torch.int32, device=enc.device)
+                ids, _ = self.model.decoder.sample_steps(enc, max_length, tok0, temperature, top_k, top_p, seed,
+                                                         stop=_lib.STOP_STICKY, end_id=end)
+            else:
+                ids, _ = self.model.greedy_ids(enc, start, end, max_length, temperature, stop=_lib.STOP_STICKY,
+                                               select=_lib.SELECT_SOFTMAX)
         end, start = self.tokenizer.end_token_id, self.tokenizer.start_token_id
         out = []
         for row in ids.cpu().tolist():
@@ -118,16 +129,14 @@ class Predictor:
         return out
 
     def predict_batch(self, images, beam_size: int = 0, max_length: int = 141, temperature: float = 1.0,
-                      top_k: int = 0, top_p: float = 0.0, batch_size: int = 16) -> List[str]:
-        """predictor.py:205-394.  As in the reference beam_size is clamped to 0 (:231-235); sampling
-        (top_k / top_p > 0, :330-331) is not built -- the deterministic branch (:333) is."""
-        if top_k > 0 or top_p > 0.0:
-            raise NotImplementedError("img2latex_amd Predictor: multinomial sampling (top_k/top_p) is not built")
+                      top_k: int = 0, top_p: float = 0.0, batch_size: int = 16, seed: Optional[int] = None) -> List[str]:
+        """predictor.py:205-394.  As in the reference beam_size is clamped to 0 (:231-235)."""
         x = self._as_batch(images)
         results: List[str] = []
         start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
         for i in range(0, x.shape[0], batch_size):
-            for seq in self.predict_batch_ids(x[i:i + batch_size], max_length, temperature):
+            for seq in self.predict_batch_ids(x[i:i + batch_size], max_length, temperature, top_k, top_p,
+                                              None if seed is None else seed + i):
                 if seq and seq[0] == start:                                 # :384-388
                     seq = seq[1:]
                 if seq and seq[-1] == end:

@@ -140,6 +140,7 @@ int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* enc, int rows
 /* Token selection. */
 #define I2L_SELECT_LOGITS 0   /* argmax(logits / temperature)           seq2seq.py:213-215      */
 #define I2L_SELECT_SOFTMAX 1  /* argmax(softmax(logits / temperature))  predictor.py:295-297,333 */
+#define I2L_SELECT_SAMPLE 2   /* multinomial over the top-k / top-p masked softmax  predictor.py:299-331 (i2l_sample_decode) */
 
 /* The decode loop: `steps` iterations of [embedding lookup, LSTM step (all layers),
  * output projection, token selection], one persistent launch, no host sync inside.
@@ -159,6 +160,17 @@ int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int r
                       float temperature, int select, int stop, int end_id,
                       int32_t* ids_out, float* logits_out, float* h_out, float* c_out,
                       i2l_stream_t stream);
+
+/* The sampling branch of Predictor.predict_batch (predictor.py:295-331, taken when temperature > 0 and
+ * (top_k > 0 or top_p > 0)): probs = softmax(logits/T); top-k keeps p >= k-th largest; top-p drops a
+ * token once the probability mass sorted ahead of it exceeds top_p; renormalise; ONE multinomial draw per
+ * row and step by inverse CDF with a counter-based uniform of (seed, row, step) -- deterministic for a
+ * seed, not bit-comparable with torch.multinomial.  probs_out (rows, steps, V) or NULL receives the final
+ * sampling distribution of every step.  vocab <= 2048. */
+int i2l_sample_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
+                      const int32_t* tok0, const float* h0, const float* c0, float temperature, int top_k,
+                      float top_p, uint64_t seed, int stop, int end_id, int32_t* ids_out, float* probs_out,
+                      float* h_out, float* c_out, i2l_stream_t stream);
 
 /* Beam search for `images` independent images, `beam` beams each (<= I2L_MAX_BEAM):
  * per image exactly Seq2SeqModel._beam_search at batch 1 (seq2seq.py:234-298) --

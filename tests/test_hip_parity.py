@@ -363,3 +363,68 @@ def test_predictor_and_checkpoint_roundtrip(tmp_path):
     assert opt.state_dict()["state"][0]["exp_avg"].shape == m2.encoder.cnn_layers[0].weight.shape
     m2.eval()
     del _MODELS[("tiny_l1", repr(None))]            # its parameters were updated by the step above
+
+
+def _uniform01(seed, row, step):
+    """Python twin of decode.hip::uniform01 (splitmix64 finaliser of (seed, row, step), 24 bits)."""
+    M = (1 << 64) - 1
+    z = (seed + (((row << 32) | step) * 0x9E3779B97F4A7C15)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z = z ^ (z >> 31)
+    return np.float32(z >> 40) * np.float32(1.0 / 16777216.0)
+
+
+@pytest.mark.parametrize("top_k,top_p,temp", [(5, 0.0, 1.0), (0, 0.8, 0.7), (7, 0.6, 1.3), (1, 0.0, 1.0)])
+def test_sampling_distribution_and_draws(top_k, top_p, temp):
+    """predictor.py:295-331: the masked / renormalised distribution equals the oracle's; every draw is the
+    inverse-CDF of that distribution at the kernel's documented uniform; same seed -> same ids."""
+    d, cfg, _ = load("tiny_l2_attn")
+    m, _ = model_for("tiny_l2_attn")
+    sd = torch_state_dict("tiny_l2_attn")
+    x = images(cfg, batch=6, seed=41)
+    seed, steps = 1234567, 6
+    with torch.no_grad():
+        enc = m.encoder(x.to(DEV))
+        tok0 = torch.full((6,), START, dtype=torch.int32, device=DEV)
+        ids, probs = m.decoder.sample_steps(enc, steps, tok0, temp, top_k, top_p, seed, stop=_lib.STOP_NONE, want_probs=True)
+        ids2, _ = m.decoder.sample_steps(enc, steps, tok0, temp, top_k, top_p, seed, stop=_lib.STOP_NONE)
+        ids3, _ = m.decoder.sample_steps(enc, steps, tok0, temp, top_k, top_p, seed + 1, stop=_lib.STOP_NONE)
+    assert torch.equal(ids, ids2)
+    ids_h, probs_h = ids.cpu().numpy(), probs.cpu().numpy()
+    # oracle: replay the decoder along the HIP-sampled tokens and rebuild the masked distribution per step
+    enc_cpu = O.cnn_encoder(sd, cfg, x)
+    tok = torch.full((6, 1), START, dtype=torch.long)
+    hidden = None
+    for t in range(steps):
+        with torch.no_grad():
+            out, hidden = O.decode_step(sd, cfg, enc_cpu, tok, hidden)
+        p = torch.softmax(out.squeeze(1) / temp, dim=-1)
+        if top_k > 0:
+            kth = torch.topk(p, min(top_k, p.size(-1)), dim=-1).values[:, -1, None]
+            p = torch.where(p < kth, torch.zeros_like(p), p)
+            p = p / p.sum(-1, keepdim=True)
+        if top_p > 0:
+            sp, si = torch.sort(p, descending=True, stable=True)
+            cum = torch.cumsum(sp, -1)
+            rm = cum > top_p
+            rm[:, 1:] = rm[:, :-1].clone()
+            rm[:, 0] = False
+            p = torch.where(rm.scatter(-1, si, rm), torch.zeros_like(p), p)
+            p = p / p.sum(-1, keepdim=True)
+        want = p.numpy()
+        close(probs_h[:, t, :], want, 1e-5)
+        for b in range(6):
+            pr = probs_h[b, t].astype(np.float32)
+            assert pr[ids_h[b, t]] > 0
+            u = _uniform01(seed, b, t)
+            cdf = np.cumsum(pr.astype(np.float64))
+            j = int(np.searchsorted(cdf, float(u) * cdf[-1], side="right"))
+            lo = cdf[j - 1] if j > 0 else 0.0
+            if min(abs(float(u) * cdf[-1] - lo), abs(cdf[min(j, len(cdf) - 1)] - float(u) * cdf[-1])) > 1e-5:
+                assert j == ids_h[b, t], (b, t, j, ids_h[b, t])
+        tok = torch.from_numpy(ids_h[:, t:t + 1].astype(np.int64))
+    if top_k != 1:
+        assert not torch.equal(ids, ids3)        # a different seed draws different tokens
+    else:
+        assert torch.equal(ids, ids3)            # top-1 sampling is greedy
