@@ -428,3 +428,32 @@ def test_sampling_distribution_and_draws(top_k, top_p, temp):
         assert not torch.equal(ids, ids3)        # a different seed draws different tokens
     else:
         assert torch.equal(ids, ids3)            # top-1 sampling is greedy
+
+
+def test_full_size_properties_cfg2():
+    """Size-independent properties at BASELINE config 2's full size (B=256, 150 steps): idempotence
+    (bit-identical reruns), batch-permutation equivariance (rows are independent), prefix property
+    (the first k steps of a longer decode equal a k-step decode), sticky-stop consistency."""
+    d, cfg, sd_kw = load("primary_cfg2_clock")
+    m, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(DEV)
+    perm = torch.from_numpy(synth.randint(3, "perm", (256,), 0, 1 << 30)).argsort().to(DEV)
+    with torch.no_grad():
+        enc = m.encoder(x)
+        enc2 = m.encoder(x)
+        ids, _ = m.greedy_ids(enc, START, END, 150)
+        ids_again, _ = m.greedy_ids(enc, START, END, 150)
+        enc_p = m.encoder(x[perm].contiguous())
+        ids_p, _ = m.greedy_ids(enc_p, START, END, 150)
+        ids_40, _ = m.greedy_ids(enc, START, END, 40)
+        ids_sticky, _ = m.greedy_ids(enc, START, END, 150, stop=_lib.STOP_STICKY)
+    assert torch.equal(enc, enc2) and torch.equal(ids, ids_again)
+    assert torch.equal(enc_p, enc[perm]) and torch.equal(ids_p, ids[perm])
+    assert torch.equal(ids_40, ids[:, :40])
+    a, s_ = ids.cpu().numpy(), ids_sticky.cpu().numpy()
+    for b in range(256):
+        ends = np.nonzero(a[b] == END)[0]
+        n = int(ends[0]) + 1 if ends.size else 150
+        assert np.array_equal(s_[b, :n], a[b, :n]) and (s_[b, n:] == -1).all()
+    # ids are valid token ids and START never reappears as an argmax artefact of padding
+    assert a.min() >= 0 and a.max() < cfg["vocab_size"]
