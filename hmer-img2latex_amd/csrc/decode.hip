@@ -421,8 +421,11 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
 #pragma unroll
         for (int k = 0; k < KR; ++k) wres[k] = *reinterpret_cast<const float4*>(w.WhhT[0] + (size_t)k * 4 * H + 4 * jj);
     }
-    float4 genc_reg = make_float4(0.f, 0.f, 0.f, 0.f);     // image half of the layer-0 gates: constant over the loop
-    if (KR + KL > 0) genc_reg = *reinterpret_cast<const float4*>(w.Genc + (size_t)grow[0] * 4 * H + 4 * jj);
+    float4 genc_reg[R];                                   // image half of the layer-0 gates: constant over the loop
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        genc_reg[r] = (KR + KL > 0) ? *reinterpret_cast<const float4*>(w.Genc + (size_t)grow[r] * 4 * H + 4 * jj)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
     if (KL > 0) {
         const float4* src = reinterpret_cast<const float4*>(w.WhhT[0] + (size_t)KR * 4 * H);
         for (int idx = tid; idx < KL * H; idx += NT) reinterpret_cast<float4*>(wl)[idx] = src[idx];
@@ -442,47 +445,62 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
         if (KR + KL > 0)
             load_batch<float4>(pre, w.WoutT + (size_t)(tid >> 7) * (H >> 1) * w.Vp + (tid & 127) * 4, (size_t)w.Vp);
         if (KR + KL > 0) {
-            // R == 1, L == 1, H <= NT: one LSTM layer, thread tid = hidden unit
+            // L == 1, H <= NT: one LSTM layer, thread tid = hidden unit, R rows share every weight read
             const size_t G = 4 * (size_t)H;
-            const float* h_old = hs + (size_t)par * H;
-            float* h_new = hs + (size_t)(par ^ 1) * H;
+            const float* h_old = hs + (size_t)par * R * H;
+            float* h_new = hs + (size_t)(par ^ 1) * R * H;
             if (tid < H) {
                 // the token-dependent row of P is only needed at the end of the chain: its L2 latency hides
-                // behind the 96 resident rows (the sum starts from the image half, which never changes)
-                const float4 a = *reinterpret_cast<const float4*>(w.P + (size_t)tok[0] * G + 4 * tid);
-                float4 acc[1] = {genc_reg};
+                // behind the resident rows (the sum starts from the image half, which never changes)
+                float4 a[R], acc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    a[r] = *reinterpret_cast<const float4*>(w.P + (size_t)tok[r] * G + 4 * tid);
+                    acc[r] = genc_reg[r];
+                }
 #pragma unroll
                 for (int k4 = 0; k4 < KR; k4 += 4) {
-                    const float4 xa = *reinterpret_cast<const float4*>(h_old + k4);
-                    const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[0].x = fmaf(wres[k4 + i].x, xv[i], acc[0].x);
-                        acc[0].y = fmaf(wres[k4 + i].y, xv[i], acc[0].y);
-                        acc[0].z = fmaf(wres[k4 + i].z, xv[i], acc[0].z);
-                        acc[0].w = fmaf(wres[k4 + i].w, xv[i], acc[0].w);
+                    for (int r = 0; r < R; ++r) {
+                        const float4 xa = *reinterpret_cast<const float4*>(h_old + r * H + k4);
+                        const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[r].x = fmaf(wres[k4 + i].x, xv[i], acc[r].x);
+                            acc[r].y = fmaf(wres[k4 + i].y, xv[i], acc[r].y);
+                            acc[r].z = fmaf(wres[k4 + i].z, xv[i], acc[r].z);
+                            acc[r].w = fmaf(wres[k4 + i].w, xv[i], acc[r].w);
+                        }
                     }
                 }
 #pragma unroll 2
                 for (int k4 = 0; k4 < KL; k4 += 4) {
-                    const float4 xa = *reinterpret_cast<const float4*>(h_old + KR + k4);
-                    const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+                    float4 wv[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float4 wv = *reinterpret_cast<const float4*>(wl + (size_t)(k4 + i) * G + 4 * tid);
-                        acc[0].x = fmaf(wv.x, xv[i], acc[0].x);
-                        acc[0].y = fmaf(wv.y, xv[i], acc[0].y);
-                        acc[0].z = fmaf(wv.z, xv[i], acc[0].z);
-                        acc[0].w = fmaf(wv.w, xv[i], acc[0].w);
+                    for (int i = 0; i < 4; ++i) wv[i] = *reinterpret_cast<const float4*>(wl + (size_t)(k4 + i) * G + 4 * tid);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float4 xa = *reinterpret_cast<const float4*>(h_old + r * H + KR + k4);
+                        const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[r].x = fmaf(wv[i].x, xv[i], acc[r].x);
+                            acc[r].y = fmaf(wv[i].y, xv[i], acc[r].y);
+                            acc[r].z = fmaf(wv[i].z, xv[i], acc[r].z);
+                            acc[r].w = fmaf(wv[i].w, xv[i], acc[r].w);
+                        }
                     }
                 }
-                matvec<1, float4>(acc, w.WhhT[0] + (size_t)(KR + KL) * G + 4 * tid, G, h_old + KR + KL, H, H - KR - KL);
-                acc[0].x += a.x; acc[0].y += a.y; acc[0].z += a.z; acc[0].w += a.w;
-                const float ig = sigmoidf_(acc[0].x), fg = sigmoidf_(acc[0].y);
-                const float gg = tanhf(acc[0].z), og = sigmoidf_(acc[0].w);
-                const float cn = fg * cs[tid] + ig * gg;
-                cs[tid] = cn;
-                h_new[tid] = og * tanhf(cn);
+                matvec<R, float4>(acc, w.WhhT[0] + (size_t)(KR + KL) * G + 4 * tid, G, h_old + KR + KL, H, H - KR - KL);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[r].x += a[r].x; acc[r].y += a[r].y; acc[r].z += a[r].z; acc[r].w += a[r].w;
+                    const float ig = sigmoidf_(acc[r].x), fg = sigmoidf_(acc[r].y);
+                    const float gg = tanhf(acc[r].z), og = sigmoidf_(acc[r].w);
+                    const float cn = fg * cs[r * H + tid] + ig * gg;
+                    cs[r * H + tid] = cn;
+                    h_new[r * H + tid] = og * tanhf(cn);
+                }
             }
             __syncthreads();
         } else {
@@ -870,6 +888,7 @@ StepWeights step_weights(const Layout& lo, const char* base, int V, int H, int L
 }
 
 constexpr int RES_KR = 76, RES_KL = 36;   // resident rows of WhhT[0]: registers / LDS (fast path)
+constexpr int RES2_KR = 64, RES2_KL = 32; // same with two rows per workgroup (a few more live registers)
 
 size_t decode_lds_bytes(int R, int L, int H, int Vp, int select, int KL = 0) {
     size_t floats = (size_t)3 * L * R * H + 4 * R + 4 * R + R + R + 4 + (size_t)R * 512 + (size_t)KL * 4 * H;
@@ -945,7 +964,19 @@ namespace {
 int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
                   const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
                   int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
-                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream);
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg = 0);
+}
+
+extern "C" int i2l_greedy_decode_ex(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
+                                    const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
+                                    float temperature, int select, int stop, int end_id, int rows_per_workgroup,
+                                    int32_t* ids_out, float* logits_out, float* h_out, float* c_out,
+                                    i2l_stream_t stream) {
+    if (select != I2L_SELECT_LOGITS && select != I2L_SELECT_SOFTMAX) return I2L_ERR_ARG;
+    if (rows_per_workgroup != 0 && rows_per_workgroup != 1 && rows_per_workgroup != 2 && rows_per_workgroup != 4)
+        return I2L_ERR_ARG;
+    return launch_decode(w, workspace, rows, steps, tok0, forced, h0, c0, temperature, select, stop, end_id, 0, 0.f, 0ull,
+                         ids_out, logits_out, nullptr, h_out, c_out, stream, rows_per_workgroup);
 }
 
 extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
@@ -971,7 +1002,7 @@ namespace {
 int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
                   const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
                   int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
-                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream) {
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg) {
     int rc = check_weights(w);
     if (rc != I2L_OK) return rc;
     if (!workspace || !tok0 || rows <= 0 || steps <= 0) return I2L_ERR_ARG;
@@ -992,6 +1023,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
 
     // rows per workgroup: fill the 256 CUs first, then stack rows (weights are streamed once per workgroup per step)
     int R = rows <= 256 ? 1 : (rows <= 512 ? 2 : 4);
+    if (rows_per_wg > 0) R = rows_per_wg;
     while (R > 1 && decode_lds_bytes(R, L, H, lo.Vp, select) > 64 * 1024) R >>= 1;
     const size_t lds = decode_lds_bytes(R, L, H, lo.Vp, select);
     if (lds > 64 * 1024) return I2L_ERR_UNSUPPORTED;
@@ -1005,10 +1037,10 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
         I2L_CHECK_LAUNCH();
         return I2L_OK;
     }
-    const bool resident = R == 1 && L == 1 && H == 256 && steps >= 8;
+    const bool resident = (R == 1 || R == 2) && L == 1 && H == 256 && steps >= 8;
     if (resident) {
-        const size_t lds_r = decode_lds_bytes(1, 1, H, lo.Vp, select, RES_KL);
-        auto kern = decode_kernel<1, RES_KR, RES_KL>;
+        const size_t lds_r = decode_lds_bytes(R, 1, H, lo.Vp, select, R == 1 ? RES_KL : RES2_KL);
+        auto kern = R == 1 ? decode_kernel<1, RES_KR, RES_KL> : decode_kernel<2, RES2_KR, RES2_KL>;
         if (lds_r <= 160 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_r) == hipSuccess) {

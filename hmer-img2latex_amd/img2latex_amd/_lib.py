@@ -60,6 +60,9 @@ _SIGNATURES = {
     "i2l_greedy_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "i2l_greedy_decode_ex": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
     "i2l_sample_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                   c_int, c_float, c_uint64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),

@@ -133,7 +133,7 @@ class LSTMDecoder(nn.Module):
                   forced: Optional[torch.Tensor] = None, hidden: Optional[Hidden] = None,
                   temperature: float = 1.0, select: int = _lib.SELECT_LOGITS, stop: int = _lib.STOP_NONE,
                   end_id: int = -1, want_ids: bool = True, want_logits: bool = False,
-                  want_state: bool = False, reuse_weight_images: bool = False):
+                  want_state: bool = False, reuse_weight_images: bool = False, rows_per_workgroup: int = 0):
         """prepare + one persistent i2l_greedy_decode launch.  Returns (ids, logits, (h, c))."""
         w, keep, enc = self.prepare(encoder_output, reuse_weight_images)
         rows, dev = enc.shape[0], enc.device
@@ -155,10 +155,10 @@ class LSTMDecoder(nn.Module):
         if want_state:
             h = torch.empty((self.lstm_layers, rows, self.hidden_dim), dtype=torch.float32, device=dev)
             c = torch.empty_like(h)
-        _lib.check(_lib.lib().i2l_greedy_decode(
+        _lib.check(_lib.lib().i2l_greedy_decode_ex(
             ctypes.byref(w), self._ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(forced), _lib.ptr(h0),
-            _lib.ptr(c0), float(temperature), select, stop, int(end_id), _lib.ptr(ids), _lib.ptr(logits),
-            _lib.ptr(h), _lib.ptr(c), _lib.stream_ptr()), "greedy_decode")
+            _lib.ptr(c0), float(temperature), select, stop, int(end_id), int(rows_per_workgroup), _lib.ptr(ids),
+            _lib.ptr(logits), _lib.ptr(h), _lib.ptr(c), _lib.stream_ptr()), "greedy_decode")
         _lib.mark("decode")
         del keep
         return ids, logits, ((h, c) if want_state else None)

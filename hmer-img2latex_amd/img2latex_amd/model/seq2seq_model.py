@@ -71,13 +71,13 @@ class Seq2SeqModel(nn.Module):
 
     def greedy_ids(self, encoder_output: torch.Tensor, start_token_id: int, end_token_id: int, max_length: int,
                    temperature: float = 1.0, stop: int = _lib.STOP_NONE, select: int = _lib.SELECT_LOGITS,
-                   want_logits: bool = False):
+                   want_logits: bool = False, rows_per_workgroup: int = 0):
         """Device-side greedy loop; returns (ids (B,T) int32 on device, logits or None)."""
         B = encoder_output.shape[0]
         tok0 = torch.full((B,), int(start_token_id), dtype=torch.int32, device=encoder_output.device)
         ids, logits, _ = self.decoder.run_steps(encoder_output, max_length, tok0, temperature=temperature,
                                                 select=select, stop=stop, end_id=end_token_id,
-                                                want_logits=want_logits)
+                                                want_logits=want_logits, rows_per_workgroup=rows_per_workgroup)
         return ids, logits
 
     def _greedy_search(self, encoder_output: torch.Tensor, start_token_id: int, end_token_id: int,

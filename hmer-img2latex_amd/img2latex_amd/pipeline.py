@@ -2,10 +2,12 @@
 
 Images are independent, so consecutive batches can overlap: the encoder of batch i+1
 (fp32-MFMA bound, thousands of short workgroups) runs on one HIP stream while the
-persistent decode loop of batch i (one workgroup per CU, bound by the L2->CU weight
-stream, mostly waiting) runs on another.  Their workgroups fit on a CU side by side
-(decode: 4 waves x 240 VGPRs; conv: 128 VGPRs, 34 KB LDS), so the hardware interleaves
-them and steady-state time per batch approaches max(encoder, decode) instead of the sum.
+persistent decode loop of batch i runs on another.  A decode workgroup owns its CU (it keeps
+~500 registers per lane of weights resident), so the decode is launched with TWO rows per
+workgroup: 128 workgroups on 128 CUs at nearly the same time per step (the weight stream of a
+workgroup is shared by its rows), which leaves the other 128 CUs to the encoder.  Steady-state
+time per batch approaches max(encoder on half the chip, decode on half the chip) instead of the
+sum on the whole chip.
 
 Nothing is skipped: every batch still runs the full encoder, decoder prepare, decode loop
 and id copy; results equal ``Seq2SeqModel._greedy_search`` batch by batch.
@@ -24,7 +26,7 @@ class GreedyPipeline:
     """submit(images) enqueues one batch; results come back in order from collect()."""
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
-                 temperature: float = 1.0, depth: int = 2):
+                 temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -34,6 +36,7 @@ class GreedyPipeline:
         self.enc_stream = torch.cuda.Stream(device=dev)
         self.dec_stream = torch.cuda.Stream(device=dev)
         self.depth = depth
+        self.rows_per_workgroup = rows_per_workgroup     # 2: decode occupies half of the CUs, the encoder the rest
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor]] = deque()
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
         self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
@@ -53,7 +56,8 @@ class GreedyPipeline:
             with torch.cuda.stream(self.dec_stream):
                 self.dec_stream.wait_event(enc_done)
                 enc.record_stream(self.dec_stream)
-                ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature)
+                ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
+                                               rows_per_workgroup=self.rows_per_workgroup)
                 host = self._host_buffer(ids.shape)
                 host.copy_(ids, non_blocking=True)
                 done = torch.cuda.Event()

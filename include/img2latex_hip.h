@@ -161,6 +161,15 @@ int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int r
                       int32_t* ids_out, float* logits_out, float* h_out, float* c_out,
                       i2l_stream_t stream);
 
+/* Same as i2l_greedy_decode with an explicit number of batch rows per workgroup (0 = automatic, else 1, 2
+ * or 4).  Rows per workgroup > 1 leaves compute units free for another stream (the weight stream of a
+ * workgroup is shared by its rows): GreedyPipeline runs the decode of batch i on half of the chip while the
+ * encoder of batch i+1 runs on the other half.  Results do not depend on this parameter. */
+int i2l_greedy_decode_ex(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
+                         const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
+                         float temperature, int select, int stop, int end_id, int rows_per_workgroup,
+                         int32_t* ids_out, float* logits_out, float* h_out, float* c_out, i2l_stream_t stream);
+
 /* The sampling branch of Predictor.predict_batch (predictor.py:295-331, taken when temperature > 0 and
  * (top_k > 0 or top_p > 0)): probs = softmax(logits/T); top-k keeps p >= k-th largest; top-p drops a
  * token once the probability mass sorted ahead of it exceeds top_p; renormalise; ONE multinomial draw per

@@ -457,3 +457,18 @@ def test_full_size_properties_cfg2():
         assert np.array_equal(s_[b, :n], a[b, :n]) and (s_[b, n:] == -1).all()
     # ids are valid token ids and START never reappears as an argmax artefact of padding
     assert a.min() >= 0 and a.max() < cfg["vocab_size"]
+
+
+def test_rows_per_workgroup_does_not_change_results():
+    """The decode result must not depend on how rows are packed into workgroups (R = 1, 2, 4; resident-weight
+    fast paths for R = 1 and R = 2)."""
+    d, cfg, sd_kw = load("primary_cfg2")
+    m, _ = model_for("primary_cfg2", sd_kw, cfg)
+    x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)[:70]).to(DEV)
+    with torch.no_grad():
+        enc = m.encoder(x)
+        base, _ = m.greedy_ids(enc, START, END, 60, rows_per_workgroup=1)
+        for r in (2, 4):
+            got, _ = m.greedy_ids(enc, START, END, 60, rows_per_workgroup=r)
+            assert torch.equal(got, base), r
+    assert np.array_equal(base.cpu().numpy(), d["ids"][:70, 1:61])
