@@ -41,8 +41,9 @@ template <int NTW>      // 32-column MFMA tiles per wave: workgroup tile = 128 x
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(BfGemm g) {
     constexpr int GN = 64 * NTW;
     constexpr int GNLW = GN * GK / 8 / 256;
-    __shared__ __attribute__((aligned(16))) bf16_t As[GM * GLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Ws[GN * GLD];
+    __shared__ __attribute__((aligned(16))) bf16_t smem_ab[(GM + GN) * GLD];
+    bf16_t* As = smem_ab;
+    bf16_t* Ws = smem_ab + GM * GLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -108,7 +109,51 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(BfGemm g) {
         }
         __syncthreads();
     }
+    // Epilogue.  The activations are far larger than the weights, so most layers are bound by writing C (and
+    // reading the residual): stage the scaled tile in LDS as bf16 and move 16 bytes per lane, whole rows at a time.
     // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    constexpr int CLD = GN + 8;                               // bf16 row stride of the staged tile (16-byte aligned rows)
+    bf16_t* Cs = As;                                          // As and Ws are adjacent: 128 x CLD bf16 fit in them
+    static_assert(GM * CLD <= GM * GLD + 64 * NTW * GLD, "staged C tile must fit in the operand tiles");
+    if (g.N % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0)) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int nl = wn * 32 * NTW + nt * 32 + li;
+            const int n = n0 + nl;
+            const float sc = (g.scale && n < g.N) ? g.scale[n] : 1.f, bi = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    // without a residual the value is final: apply ReLU before the single rounding to bf16
+                    float v = acc[mt][nt][r] * sc + bi;
+                    if (g.relu && !g.res) v = fmaxf(v, 0.f);
+                    Cs[ml * CLD + nl] = f2bf(v);
+                }
+        }
+        __syncthreads();
+        constexpr int CHUNKS = GN / 8;                        // 16-byte chunks per row
+        for (int idx = tid; idx < GM * CHUNKS; idx += 256) {
+            const int ml = idx / CHUNKS, c8 = (idx - ml * CHUNKS) * 8;
+            const int m = m0 + ml, n = n0 + c8;
+            if (m >= g.M || n >= g.N) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(&Cs[ml * CLD + c8]);
+            if (g.res) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(g.res + (size_t)m * g.ldr + n);
+                bf16_t* hv = reinterpret_cast<bf16_t*>(&v);
+                const bf16_t* hr = reinterpret_cast<const bf16_t*>(&rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f(hv[e]) + bf2f(hr[e]);
+                    if (g.relu) f = fmaxf(f, 0.f);
+                    hv[e] = f2bf(f);
+                }
+            }
+            *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = n0 + wn * 32 * NTW + nt * 32 + li;
