@@ -325,25 +325,61 @@ int grid_for(size_t n) {
 
 }  // namespace
 
+namespace {
+struct PackLayout { size_t wp, scale, bias, total; int Kp; };
+PackLayout pack_layout(int Cout, int Cin, int kh, int kw) {
+    PackLayout o{};
+    o.Kp = i2l_cdiv(kh * kw * Cin, 8) * 8;
+    o.wp = 0;
+    o.scale = i2l_align((size_t)Cout * o.Kp * sizeof(bf16_t));
+    o.bias = o.scale + i2l_align((size_t)Cout * sizeof(float));
+    o.total = o.bias + i2l_align((size_t)Cout * sizeof(float));
+    return o;
+}
+}  // namespace
+
+extern "C" size_t i2l_conv_bf16_packed_bytes(int Cout, int Cin, int kh, int kw) {
+    if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return pack_layout(Cout, Cin, kh, kw).total;
+}
+
+// Weight-only preparation of one conv + BatchNorm pair: bf16 [Cout][taps*Cin] image and the folded
+// scale/bias.  Valid until a weight or a BatchNorm statistic changes.
+extern "C" int i2l_conv_bn_bf16_pack(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                                      const float* bn_var, float bn_eps, void* packed, size_t packed_bytes, int Cout,
+                                      int Cin, int kh, int kw, i2l_stream_t stream) {
+    if (!w || !bn_weight || !bn_bias || !bn_mean || !bn_var || !packed || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0)
+        return I2L_ERR_ARG;
+    const PackLayout lo = pack_layout(Cout, Cin, kh, kw);
+    if (packed_bytes < lo.total) return I2L_ERR_WORKSPACE;
+    hipStream_t s = i2l_s(stream);
+    char* base = static_cast<char*>(packed);
+    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(grid_for((size_t)Cout * lo.Kp)), dim3(256), 0, s, w,
+                       reinterpret_cast<bf16_t*>(base + lo.wp), Cout, Cin, kh * kw, lo.Kp);
+    I2L_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_bn_kernel, dim3(i2l_cdiv(Cout, 256)), dim3(256), 0, s, bn_weight, bn_bias, bn_mean, bn_var,
+                       bn_eps, reinterpret_cast<float*>(base + lo.scale), reinterpret_cast<float*>(base + lo.bias), Cout);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
 extern "C" size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
                                                 int pad) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return 0;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
     const int Kp = i2l_cdiv(kh * kw * Cin, 8) * 8;
-    size_t bytes = i2l_align((size_t)Cout * Kp * sizeof(bf16_t)) + 2 * i2l_align((size_t)Cout * sizeof(float));
     const bool direct = kh == 1 && kw == 1 && stride == 1 && pad == 0 && Cin % 8 == 0;
-    if (!direct) bytes += i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
-    return bytes;
+    return direct ? 256 : i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
 }
 
-// y = act( BN(conv(x, w)) + residual ), NHWC bf16 in/out (x may instead be the NCHW fp32 image batch).
-extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const float* w, const float* bn_weight,
-                                         const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps,
-                                         const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int kh,
-                                         int kw, int stride, int pad, int relu, void* workspace, size_t workspace_bytes,
+// y = act( BN(conv(x, w)) + residual ), NHWC bf16 in/out (x may instead be the NCHW fp32 image batch);
+// `packed` comes from i2l_conv_bn_bf16_pack for the same conv.
+extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const void* packed, const void* residual,
+                                         void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                         int pad, int relu, void* workspace, size_t workspace_bytes,
                                          i2l_stream_t stream) {
-    if (!x || !w || !y || !bn_weight || !bn_bias || !bn_mean || !bn_var) return I2L_ERR_ARG;
+    if (!x || !packed || !y) return I2L_ERR_ARG;
     const size_t need = i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad);
     if (need == 0) return I2L_ERR_ARG;
     if (!workspace || workspace_bytes < need) return I2L_ERR_WORKSPACE;
@@ -351,19 +387,14 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     if (Cout % 8 != 0) return I2L_ERR_UNSUPPORTED;
     hipStream_t s = i2l_s(stream);
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
-    const int taps = kh * kw, Kp = i2l_cdiv(taps * Cin, 8) * 8;
-    char* base = static_cast<char*>(workspace);
-    bf16_t* wp = reinterpret_cast<bf16_t*>(base);
-    size_t off = i2l_align((size_t)Cout * Kp * sizeof(bf16_t));
-    float* scale = reinterpret_cast<float*>(base + off); off += i2l_align((size_t)Cout * sizeof(float));
-    float* bias = reinterpret_cast<float*>(base + off); off += i2l_align((size_t)Cout * sizeof(float));
-    bf16_t* col = reinterpret_cast<bf16_t*>(base + off);
-
-    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(grid_for((size_t)Cout * Kp)), dim3(256), 0, s, w, wp, Cout, Cin, taps, Kp);
-    I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fold_bn_kernel, dim3(i2l_cdiv(Cout, 256)), dim3(256), 0, s, bn_weight, bn_bias, bn_mean, bn_var,
-                       bn_eps, scale, bias, Cout);
-    I2L_CHECK_LAUNCH();
+    const int taps = kh * kw;
+    const PackLayout lo = pack_layout(Cout, Cin, kh, kw);
+    const int Kp = lo.Kp;
+    const char* pbase = static_cast<const char*>(packed);
+    const bf16_t* wp = reinterpret_cast<const bf16_t*>(pbase + lo.wp);
+    const float* scale = reinterpret_cast<const float*>(pbase + lo.scale);
+    const float* bias = reinterpret_cast<const float*>(pbase + lo.bias);
+    bf16_t* col = static_cast<bf16_t*>(workspace);
     const size_t M = (size_t)B * Ho * Wo;
     if (M > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
     BfGemm g{};

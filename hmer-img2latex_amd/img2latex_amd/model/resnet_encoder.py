@@ -100,6 +100,8 @@ class ResNetEncoder(nn.Module):
         self.activation = nn.ReLU()
         self.model_name = model_name
         self._ws: Optional[torch.Tensor] = None
+        self._packed = {}          # id(conv) -> (version key, packed bf16 filter + folded BatchNorm)
+        self.cache_packed_weights = True
 
     # ------------------------------------------------------------------
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -113,15 +115,36 @@ class ResNetEncoder(nn.Module):
         k, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         Ho, Wo = (H + 2 * pd - k) // s + 1, (W + 2 * pd - k) // s + 1
         L = _lib.lib()
+        packed = self._packed_weights(conv, bn, x.device)
         y = torch.empty((B, Ho, Wo, conv.out_channels), dtype=torch.bfloat16, device=x.device)
         nbytes = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, conv.out_channels, k, k, s, pd)
         ws = self._workspace(nbytes, x.device)
         _lib.check(L.i2l_conv_bn_act_bf16_fwd(
-            x.data_ptr(), 1 if nchw_f32 else 0, conv.weight.detach().data_ptr(), bn.weight.detach().data_ptr(),
-            bn.bias.detach().data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
-            _lib.ptr(residual), y.data_ptr(), B, H, W, Cin, conv.out_channels, k, k, s, pd, 1 if relu else 0,
-            ws.data_ptr(), nbytes, _lib.stream_ptr()), "conv_bn_act_bf16_fwd")
+            x.data_ptr(), 1 if nchw_f32 else 0, packed.data_ptr(), _lib.ptr(residual), y.data_ptr(), B, H, W, Cin,
+            conv.out_channels, k, k, s, pd, 1 if relu else 0, ws.data_ptr(), nbytes, _lib.stream_ptr()),
+            "conv_bn_act_bf16_fwd")
         return y, (B, Ho, Wo, conv.out_channels)
+
+    def _packed_weights(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, device) -> torch.Tensor:
+        """bf16 filter image + BatchNorm folded into scale/bias (i2l_conv_bn_bf16_pack): weight-only work, redone
+        whenever a weight or a BatchNorm statistic changed (or on every call with cache_packed_weights = False)."""
+        tensors = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self._packed.get(id(conv))
+        if self.cache_packed_weights and hit is not None and hit[0] == key and hit[1].device == device:
+            return hit[1]
+        L = _lib.lib()
+        k = conv.kernel_size[0]
+        nbytes = L.i2l_conv_bf16_packed_bytes(conv.out_channels, conv.in_channels, k, k)
+        buf = hit[1] if hit is not None and hit[1].numel() >= nbytes and hit[1].device == device else \
+            torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.check(L.i2l_conv_bn_bf16_pack(conv.weight.detach().data_ptr(), bn.weight.detach().data_ptr(),
+                                           bn.bias.detach().data_ptr(), bn.running_mean.data_ptr(),
+                                           bn.running_var.data_ptr(), float(bn.eps), buf.data_ptr(), nbytes,
+                                           conv.out_channels, conv.in_channels, k, k, _lib.stream_ptr()),
+                   "conv_bn_bf16_pack")
+        self._packed[id(conv)] = (key, buf)
+        return buf
 
     def trunk(self, x: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) fp32 -> (B, 512|2048) fp32: the torchvision trunk incl. global average pooling."""

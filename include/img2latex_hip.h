@@ -81,14 +81,18 @@ int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, cons
 /* ResNet encoder building blocks (reference encoder.py:132-249: torchvision ResNet trunk at :242),
  * inference, bf16 on the matrix cores with fp32 accumulation.  Activations are NHWC bf16 (void*).
  *   y = act( BatchNorm_eval(conv(x, w)) + residual )    w (Cout,Cin,kh,kw) fp32, bn_* (Cout) fp32
+ * i2l_conv_bn_bf16_pack is the weight-only preparation (bf16 filter image, BatchNorm folded into
+ * scale/bias); its result stays valid until a weight or BatchNorm statistic changes.
  * x is NHWC bf16 (B,H,W,Cin), or the NCHW fp32 image batch when x_is_nchw_f32 != 0 (the stem);
  * residual is NHWC bf16 (B,Ho,Wo,Cout) or NULL; y NHWC bf16 (B,Ho,Wo,Cout). */
+size_t i2l_conv_bf16_packed_bytes(int Cout, int Cin, int kh, int kw);
+int i2l_conv_bn_bf16_pack(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                          const float* bn_var, float bn_eps, void* packed, size_t packed_bytes, int Cout,
+                          int Cin, int kh, int kw, i2l_stream_t stream);
 size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
-int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const float* w, const float* bn_weight,
-                             const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps,
-                             const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int kh,
-                             int kw, int stride, int pad, int relu, void* workspace, size_t workspace_bytes,
-                             i2l_stream_t stream);
+int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const void* packed, const void* residual,
+                             void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                             int pad, int relu, void* workspace, size_t workspace_bytes, i2l_stream_t stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) on NHWC bf16: (B,H,W,C) -> (B,(H-1)/2+1,(W-1)/2+1,C). */
 int i2l_maxpool3x3s2_bf16_fwd(const void* x, void* y, int B, int H, int W, int C, i2l_stream_t stream);
 /* nn.AdaptiveAvgPool2d(1) + Flatten: NHWC bf16 (B,H,W,C) -> fp32 (B,C). */
