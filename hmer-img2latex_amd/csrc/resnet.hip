@@ -29,6 +29,9 @@ constexpr int GM = 128, GK = 64, GLD = 72;      // LDS row stride 72 bf16 = 144 
 constexpr int GNL = GM * GK / 8 / 256;                     // 16-byte loads per thread per operand tile
 
 struct BfGemm {
+    // conv != 0: A is never materialised -- row m = (b, yo, xo) and k = (tap, ci) index the NHWC activation
+    // tensor directly (implicit GEMM; Cin % 64 == 0 so a 64-wide K tile lies inside one tap)
+    int conv, iH, iW, Cin, Ho, Wo, kw, stride, pad;
     const bf16_t* A; long lda;
     const bf16_t* W; long ldw;
     const float* scale; const float* bias;
@@ -58,14 +61,38 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(BfGemm g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     uint4 ra[GNL], rw[GNLW];
+    // implicit-GEMM rows: output pixel of each of this thread's GNL staging rows
+    int pb[GNL], py[GNL], px[GNL];
+    if (g.conv) {
+#pragma unroll
+        for (int i = 0; i < GNL; ++i) {
+            const int m = min(m0 + (tid + i * 256) / (GK / 8), g.M - 1);
+            const int xo = m % g.Wo, t = m / g.Wo;
+            pb[i] = t / g.Ho;
+            py[i] = (t - pb[i] * g.Ho) * g.stride - g.pad;
+            px[i] = xo * g.stride - g.pad;
+        }
+    }
     auto fetch = [&](int k0) {                             // global -> registers
+        int ky = 0, kx = 0, c0 = 0;
+        if (g.conv) {
+            const int tap = k0 / g.Cin;
+            c0 = k0 - tap * g.Cin;
+            ky = tap / g.kw;
+            kx = tap - ky * g.kw;
+        }
 #pragma unroll
         for (int i = 0; i < GNL; ++i) {
             const int idx = tid + i * 256;                 // 128 rows x (GK/8) chunks of 8 bf16
             const int row = idx / (GK / 8), c8 = (idx % (GK / 8)) * 8;
             ra[i] = make_uint4(0, 0, 0, 0);
-            if (k0 + c8 < g.K && m0 + row < g.M)           // K % 8 == 0
+            if (g.conv) {
+                const int yi = py[i] + ky, xi = px[i] + kx;
+                if (m0 + row < g.M && yi >= 0 && yi < g.iH && xi >= 0 && xi < g.iW)
+                    ra[i] = *reinterpret_cast<const uint4*>(g.A + (((size_t)pb[i] * g.iH + yi) * g.iW + xi) * g.Cin + c0 + c8);
+            } else if (k0 + c8 < g.K && m0 + row < g.M) {  // K % 8 == 0
                 ra[i] = *reinterpret_cast<const uint4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + c8);
+            }
         }
 #pragma unroll
         for (int i = 0; i < GNLW; ++i) {
@@ -370,7 +397,8 @@ extern "C" size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, in
     if (Ho <= 0 || Wo <= 0) return 0;
     const int Kp = i2l_cdiv(kh * kw * Cin, 8) * 8;
     const bool direct = kh == 1 && kw == 1 && stride == 1 && pad == 0 && Cin % 8 == 0;
-    return direct ? 256 : i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
+    const bool implicit = Cin % 64 == 0;                   // NHWC input gathered inside the GEMM (no im2col image)
+    return (direct || implicit) ? 256 : i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
 }
 
 // y = act( BN(conv(x, w)) + residual ), NHWC bf16 in/out (x may instead be the NCHW fp32 image batch);
@@ -399,8 +427,12 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     if (M > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
     BfGemm g{};
     const bool direct = !x_is_nchw_f32 && kh == 1 && kw == 1 && stride == 1 && pad == 0;
+    const bool implicit = !x_is_nchw_f32 && !direct && Cin % 64 == 0;
     if (direct) {
         g.A = static_cast<const bf16_t*>(x); g.lda = Cin;
+    } else if (implicit) {
+        g.conv = 1; g.iH = H; g.iW = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.kw = kw; g.stride = stride; g.pad = pad;
+        g.A = static_cast<const bf16_t*>(x); g.lda = 0;
     } else {
         const size_t stem_lds = (size_t)Cin * kh * ((STEM_TW - 1) * stride + kw) * sizeof(float);
         if (x_is_nchw_f32 && stem_lds <= 48 * 1024 && Ho <= 65535 && B <= 65535)
