@@ -77,8 +77,9 @@ class LSTMDecoder(nn.Module):
             self.attention = Attention(hidden_dim, embedding_dim)
         self.output_layer = nn.Linear(hidden_dim, vocab_size)
         self.dropout_layer = nn.Dropout(dropout)
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None      # workspace of the CURRENT stream (see _select_workspace)
         self._ws_key = None          # (rows, weight versions) the weight images in _ws were built for
+        self._ws_by_stream = {}      # stream handle -> (workspace, key): concurrent decodes must not share one
 
     # ------------------------------------------------------------------ plumbing
     def _weights_struct(self):
@@ -118,6 +119,8 @@ class LSTMDecoder(nn.Module):
             raise RuntimeError("img2latex_amd: decoder dimensions not supported by the HIP kernels")
         key = (rows, enc.device, self._weights_version())
         what = _lib.PREP_ALL
+        sid = _lib.stream_ptr()
+        self._ws, self._ws_key = self._ws_by_stream.get(sid, (None, None))
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != enc.device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
             self._ws_key = None
@@ -126,6 +129,7 @@ class LSTMDecoder(nn.Module):
         _lib.check(L.i2l_decoder_prepare(ctypes.byref(w), enc.data_ptr(), rows, what, self._ws.data_ptr(),
                                          self._ws.numel(), _lib.stream_ptr()), "decoder_prepare")
         self._ws_key = key
+        self._ws_by_stream[sid] = (self._ws, key)
         _lib.mark("prepare")
         return w, keep, enc
 

@@ -26,7 +26,7 @@ class GreedyPipeline:
     """submit(images) enqueues one batch; results come back in order from collect()."""
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
-                 temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2):
+                 temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -34,8 +34,11 @@ class GreedyPipeline:
             raise RuntimeError("img2latex_amd: GreedyPipeline needs the model on a ROCm device (no CPU fallback)")
         self.device = dev
         self.enc_stream = torch.cuda.Stream(device=dev)
-        self.dec_stream = torch.cuda.Stream(device=dev)
-        self.depth = depth
+        # several decode streams (round robin) let decodes of consecutive batches run side by side, each on
+        # few CUs (more rows per workgroup = less weight traffic per row); depth must cover them
+        self.dec_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, decode_streams))]
+        self._next_dec = 0
+        self.depth = max(depth, len(self.dec_streams) + 1)
         self.rows_per_workgroup = rows_per_workgroup     # 2: decode occupies half of the CUs, the encoder the rest
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor]] = deque()
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
@@ -53,15 +56,17 @@ class GreedyPipeline:
                 enc_done = torch.cuda.Event()
                 enc_done.record(self.enc_stream)
             images.record_stream(self.enc_stream)
-            with torch.cuda.stream(self.dec_stream):
-                self.dec_stream.wait_event(enc_done)
-                enc.record_stream(self.dec_stream)
+            dec_stream = self.dec_streams[self._next_dec]
+            self._next_dec = (self._next_dec + 1) % len(self.dec_streams)
+            with torch.cuda.stream(dec_stream):
+                dec_stream.wait_event(enc_done)
+                enc.record_stream(dec_stream)
                 ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
                                                rows_per_workgroup=self.rows_per_workgroup)
                 host = self._host_buffer(ids.shape)
                 host.copy_(ids, non_blocking=True)
                 done = torch.cuda.Event()
-                done.record(self.dec_stream)
+                done.record(dec_stream)
         self._inflight.append((done, host))
 
     def _host_buffer(self, shape) -> torch.Tensor:
