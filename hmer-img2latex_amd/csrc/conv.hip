@@ -404,7 +404,12 @@ extern "C" size_t i2l_conv_workspace_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cout % 32 != 0) return 0;
     const int cb = mfma_ci_blk(Cin), cob = mfma_co_blk(Cout);
     const int n_chunks = i2l_cdiv(Cin, cb), co_blocks = i2l_cdiv(Cout, cob);
-    return i2l_align((size_t)co_blocks * n_chunks * (cb / 2) * 9 * 2 * cob * sizeof(float));
+    size_t need = i2l_align((size_t)co_blocks * n_chunks * (cb / 2) * 9 * 2 * cob * sizeof(float));
+    if (i2l_conv_bf16x3_applicable(Cin, Cout)) {
+        const size_t n3 = i2l_conv_bf16x3_workspace_bytes(Cin, Cout);
+        if (n3 > need) need = n3;
+    }
+    return need;
 }
 
 namespace {
@@ -453,6 +458,9 @@ extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const 
                                            unsigned char* argmax_out, int B, int Cin, int H, int W, int Cout,
                                            void* workspace, size_t workspace_bytes, i2l_stream_t stream) {
     if (!x || !w || !bias || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2) return I2L_ERR_ARG;
+    // inference forward (no argmax wanted): split-bf16 matrix-core kernel where the channel counts allow
+    if (!argmax_out && i2l_conv_bf16x3_applicable(Cin, Cout))
+        return i2l_conv_bf16x3_run(x, w, bias, y, nullptr, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
     return run_conv(true, x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
 }
 

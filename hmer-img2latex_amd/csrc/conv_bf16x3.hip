@@ -1,0 +1,323 @@
+// Fused Conv2d(3x3, pad 1) + bias + ReLU + MaxPool2d(2) on the bf16 matrix cores with fp32-grade accuracy.
+//
+// Every fp32 operand is split into three bf16 pieces, x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1): 3 x 8 = 24 mantissa bits, the splits are exact in fp32), and a product a*b is
+// evaluated as the six partial products a_i * b_j with i + j <= 2 on v_mfma_f32_32x32x16_bf16.  A bf16 x bf16
+// product is exact in fp32 and the matrix core accumulates in fp32, so the result carries the same ~2^-24
+// relative error class as an fp32 fmaf chain (the dropped terms are <= 2^-24 |a||b|), while the bf16 MFMA
+// runs at 16x the fp32 MFMA rate: 6 MFMAs replace 8 for every 16 k, at 1/2 the cycles each -> 2.7x faster
+// than the exact-fp32 kernel of conv.hip.  It is NOT bit-identical to an fp32 fmaf chain; results stay within
+// the encoder tolerance (1e-5 relative, tests/test_hip_parity.py).  I2L_CONV_EXACT_FP32=1 selects conv.hip's
+// exact kernel instead.
+//
+// Tiling is the one of conv.hip: MFMA row i = 4*pp + 2*dy + dx (whole 2x2 pooling quads per lane), column =
+// output channel, workgroup = 4 waves x (2 M-tiles x 2 N-tiles) = 8x32 or 16x16 conv positions x 64 channels.
+// K order is (tap, 16 input channels): one MFMA k-step = 16 channels at one tap, lane half lh supplies channels
+// 8*lh..8*lh+7, so operands are 16-byte ds_read_b128 from channels-last LDS images
+//     in_s[split][row][lh][col (padded: row pairs land on disjoint halves of the 256-byte bank row)][8]
+//     w_s [tap][split][lh][64 channels][8]
+// Input channels go in chunks of 16: the next chunk (fp32 NCHW patch + pre-split weight slab) is prefetched into
+// registers while the 216 MFMAs of the current chunk run; the fp32 -> 3 x bf16 split happens on the way to LDS.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void split3(float x, bf16_t& s0, bf16_t& s1, bf16_t& s2) {
+    s0 = f2bf(x);
+    const float r1 = x - bf2f(s0);
+    s1 = f2bf(r1);
+    s2 = f2bf(r1 - bf2f(s1));
+}
+
+constexpr int CH = 16;                        // input channels per chunk (= one MFMA k-step per tap)
+constexpr int CO_BLK = 64;
+constexpr int W_SLAB_U4 = 9 * 3 * 2 * CO_BLK;   // 16-byte pieces of one weight chunk slab (55,296 B)
+constexpr int W_PHASE_U4 = W_SLAB_U4 / 3;      // one filter row (3 taps) of it: what LDS holds at a time
+
+template <int WX> struct Tile3 {
+    static constexpr int TR = (4 / WX) * 4, TC = WX * 16;
+    static constexpr int IR = TR + 2, IC = TC + 2;
+    static constexpr int ICP = WX == 2 ? 36 : (WX == 1 ? 20 : 68);   // padded columns: 2*ICP*16 B == 128 (mod 256)
+    static constexpr int ROW16 = 2 * ICP;               // 16-byte pieces per (split, row): [lh][col]
+    static constexpr int IN_U4 = 3 * IR * ROW16;        // 16-byte pieces of the input image
+};
+
+// wpack3[cb][chunk][tap][split][lh][co 64][8] = split_s( w[cb*64+co][chunk*16 + 8*lh + j][tap] )
+__global__ void conv_pack3_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cin, int Cout, int n_chunks,
+                                  size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (.., co, j) of split 0
+    if (idx >= total) return;
+    size_t r = idx;
+    const int j = (int)(r % 8); r /= 8;
+    const int co_l = (int)(r % CO_BLK); r /= CO_BLK;
+    const int lh = (int)(r % 2); r /= 2;
+    const int tap = (int)(r % 9); r /= 9;
+    const int chunk = (int)(r % n_chunks);
+    const int cb = (int)(r / n_chunks);
+    const int co = cb * CO_BLK + co_l, ci = chunk * CH + 8 * lh + j;
+    const float v = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+    bf16_t s[3];
+    split3(v, s[0], s[1], s[2]);
+    const size_t slab = ((size_t)cb * n_chunks + chunk) * (size_t)W_SLAB_U4 * 8;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp)
+        wp[slab + ((((size_t)tap * 3 + sp) * 2 + lh) * CO_BLK + co_l) * 8 + j] = s[sp];
+}
+
+template <int WX>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
+    const float* __restrict__ x, const bf16_t* __restrict__ wpack, const float* __restrict__ bias,
+    float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
+    int tiles_x, int n_chunks) {
+    typedef Tile3<WX> TL;
+    constexpr int PR = TL::TR / 2, PC = TL::TC / 2;
+    constexpr int OUT_F = CO_BLK * 65;                              // fp32 staging of the pooled tile
+    constexpr int IN_BYTES = TL::IN_U4 * 16 > OUT_F * 4 ? TL::IN_U4 * 16 : OUT_F * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char in_raw[IN_BYTES];
+    __shared__ __attribute__((aligned(16))) uint4 w_s[W_PHASE_U4];             // the 3 taps of one filter row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave / WX, wx = wave % WX;
+    const int cb = blockIdx.x;
+    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+    const int b = blockIdx.z;
+    const int y0 = ty * TL::TR, x0 = tx * TL::TC;
+    const int i = lane & 31, h = lane >> 5;
+    const int dx = i & 1, dy = (i >> 1) & 1, pp = i >> 2;
+    // operand bases in 16-byte pieces
+    const int a_base = ((wy * 4 + dy) * 2 + h) * TL::ICP + wx * 16 + 2 * pp + dx;
+    const int b_base = h * CO_BLK + i;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const float* xb = x + (size_t)b * Cin * H * W;
+    const uint4* wp_cb = reinterpret_cast<const uint4*>(wpack) + (size_t)cb * n_chunks * W_SLAB_U4;
+
+    // staging plan: piece e of this thread = 8 consecutive channels (half lh) of patch position (r, col)
+    constexpr int NP = TL::IR * 2 * TL::IC;
+    constexpr int NE = (NP + 255) / 256;
+    constexpr int NWV = (W_PHASE_U4 + 255) / 256;
+    constexpr int SPLIT_U4 = TL::IR * TL::ROW16;                    // 16-byte pieces between split planes
+    int loff[NE], goff[NE];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int idx = tid + e * 256;
+        const int col = idx % TL::IC;
+        const int lh = (idx / TL::IC) & 1;
+        const int r = idx / (2 * TL::IC);
+        const int iy = y0 - 1 + r, ix = x0 - 1 + col;
+        loff[e] = idx < NP ? (r * 2 + lh) * TL::ICP + col : -1;
+        goff[e] = (8 * lh * H + iy) * W + ix;
+        if (idx < NP && iy >= 0 && iy < H && ix >= 0 && ix < W) okmask |= 1u << e;
+    }
+    const int HW = H * W;
+    float xin[NE][8];
+    uint4 win[NWV];
+    auto fetch_x = [&](int chunk) {
+        const float* xc = xb + (size_t)chunk * CH * HW;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const bool ok = (okmask >> e) & 1u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xin[e][j] = ok ? xc[goff[e] + j * HW] : 0.f;
+        }
+    };
+    auto fetch_w = [&](int phase) {                                 // phase = chunk * 3 + filter row
+        const uint4* wsrc = wp_cb + (size_t)phase * W_PHASE_U4;
+#pragma unroll
+        for (int e = 0; e < NWV; ++e) {
+            const int idx = tid + e * 256;
+            win[e] = idx < W_PHASE_U4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4* in_w = reinterpret_cast<uint4*>(in_raw);
+    auto commit_x = [&]() {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (loff[e] >= 0) {
+                bf16_t s[3][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split3(xin[e][j], s[0][j], s[1][j], s[2][j]);
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    uint4 t;
+                    t.x = (unsigned)s[sp][0] | ((unsigned)s[sp][1] << 16);
+                    t.y = (unsigned)s[sp][2] | ((unsigned)s[sp][3] << 16);
+                    t.z = (unsigned)s[sp][4] | ((unsigned)s[sp][5] << 16);
+                    t.w = (unsigned)s[sp][6] | ((unsigned)s[sp][7] << 16);
+                    in_w[loff[e] + sp * SPLIT_U4] = t;
+                }
+            }
+        }
+    };
+    auto commit_w = [&]() {
+#pragma unroll
+        for (int e = 0; e < NWV; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < W_PHASE_U4) w_s[idx] = win[e];
+        }
+    };
+
+    // Two workgroups share a CU (LDS 2 x ~53 KB, <= 256 registers): while one sits in its barriers / staging the
+    // other keeps the matrix cores busy.  Per chunk: 3 phases (filter rows) of 3 taps x 24 MFMAs per wave.
+    const uint4* in_u4 = reinterpret_cast<const uint4*>(in_raw);
+    const int n_phases = 3 * n_chunks;
+    fetch_x(0);
+    fetch_w(0);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            __syncthreads();
+            if (ky == 0) commit_x();
+            commit_w();
+            __syncthreads();
+            if (chunk * 3 + ky + 1 < n_phases) fetch_w(chunk * 3 + ky + 1);
+            if (ky == 0 && chunk + 1 < n_chunks) fetch_x(chunk + 1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                bf16x8 a[2][3], bw[2][3];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) {
+                        const uint4 t = in_u4[a_base + (sp * TL::IR + m * 2 + ky) * TL::ROW16 + kx];
+                        a[m][sp] = *reinterpret_cast<const bf16x8*>(&t);
+                    }
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) {
+                        const uint4 t = w_s[b_base + ((kx * 3 + sp) * 2) * CO_BLK + n * 32];
+                        bw[n][sp] = *reinterpret_cast<const bf16x8*>(&t);
+                    }
+            // smallest partial products first; consecutive MFMAs go to different accumulators
+            constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][TI[t]], bw[n][TJ[t]], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (same lane layout as conv.hip): registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h
+    const int py0 = y0 >> 1, px0 = x0 >> 1;
+    float* out_s = reinterpret_cast<float*>(in_raw);
+    if (amax == nullptr && (Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float bv = bias[cb * CO_BLK + n * 32 + i];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
+                                          fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
+                    out_s[(n * 32 + i) * 65 + (wy * 2 + m) * PC + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < CO_BLK * 16; idx += 256) {
+            constexpr int XG = PC / 4;
+            const int x4 = idx % XG, py = (idx / XG) % PR, co_l = idx >> 4;
+            const float* sp = &out_s[co_l * 65 + py * PC + 4 * x4];
+            *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * CO_BLK + co_l) * Hp + py0 + py) * Wp + px0 + 4 * x4) =
+                make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int co = cb * CO_BLK + n * 32 + i;
+        if (co >= Cout) continue;
+        const float bv = bias[co];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int py = py0 + wy * 2 + m;
+            if (py >= Hp) continue;
+            const size_t rowoff = (((size_t)b * Cout + co) * Hp + py) * Wp;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int px = px0 + wx * 8 + 2 * q + h;
+                float best = acc[m][n][4 * q];
+                int bi = 0;
+#pragma unroll
+                for (int e = 1; e < 4; ++e)
+                    if (acc[m][n][4 * q + e] > best) { best = acc[m][n][4 * q + e]; bi = e; }
+                if (px < Wp) {
+                    y[rowoff + px] = fmaxf(best + bv, 0.f);
+                    if (amax) amax[rowoff + px] = (unsigned char)bi;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool i2l_conv_bf16x3_applicable(int Cin, int Cout) {
+    static const bool exact = getenv("I2L_CONV_EXACT_FP32") != nullptr && atoi(getenv("I2L_CONV_EXACT_FP32")) != 0;
+    return !exact && Cin % CH == 0 && Cout % CO_BLK == 0;
+}
+
+size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout) {
+    return i2l_align((size_t)(Cout / CO_BLK) * (Cin / CH) * W_SLAB_U4 * 16);
+}
+
+int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
+                        int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    if (workspace_bytes < i2l_conv_bf16x3_workspace_bytes(Cin, Cout) || !workspace) return I2L_ERR_WORKSPACE;
+    const int Hp = H / 2, Wp = W / 2;
+    const int n_chunks = Cin / CH, co_blocks = Cout / CO_BLK;
+    bf16_t* wp = static_cast<bf16_t*>(workspace);
+    const size_t total = (size_t)co_blocks * n_chunks * 9 * 2 * CO_BLK * 8;
+    hipLaunchKernelGGL(conv_pack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout,
+                       n_chunks, total);
+    I2L_CHECK_LAUNCH();
+    const int rows = 2 * Hp, cols = 2 * Wp;
+    // tile shape with the fewest wasted positions (8x32, 16x16 or 4x64; ties: 8x32)
+    int wx = 2;
+    long bestw = -1;
+    const int cand[3] = {2, 1, 4};
+    for (int c = 0; c < 3; ++c) {
+        const int tr = (4 / cand[c]) * 4, tc = cand[c] * 16;
+        const long cover = (long)i2l_cdiv(rows, tr) * tr * i2l_cdiv(cols, tc) * tc;
+        if (bestw < 0 || cover < bestw) { bestw = cover; wx = cand[c]; }
+    }
+    const int tr = (4 / wx) * 4, tc = wx * 16;
+    const int tiles_x = i2l_cdiv(cols, tc), tiles_y = i2l_cdiv(rows, tr);
+    if ((long long)tiles_x * tiles_y > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
+    dim3 grid(co_blocks, tiles_x * tiles_y, B);
+#define I2L_LAUNCH3(WXV)                                                                                              \
+    hipLaunchKernelGGL(conv3x3_bf16x3_kernel<WXV>, grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, amax, Cin, H, W, \
+                       Cout, Hp, Wp, tiles_x, n_chunks)
+    if (wx == 2) I2L_LAUNCH3(2);
+    else if (wx == 1) I2L_LAUNCH3(1);
+    else I2L_LAUNCH3(4);
+#undef I2L_LAUNCH3
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}

@@ -187,7 +187,10 @@ def test_conv_kernel_odd_shapes():
     L = _lib.lib()
     for (B, Cin, H, W, Cout) in [(1, 1, 2, 2, 1), (2, 3, 7, 9, 5), (3, 5, 16, 70, 9), (2, 16, 33, 131, 24),
                                  (1, 64, 16, 80, 128), (2, 3, 64, 320, 32), (2, 5, 23, 71, 96), (3, 9, 7, 9, 32),
-                                 (1, 32, 32, 160, 64), (2, 1, 2, 2, 64)]:
+                                 (1, 32, 32, 160, 64), (2, 1, 2, 2, 64),
+                                 # split-bf16 matrix-core kernel: every tile shape, ragged edges, 3 chunks
+                                 (2, 16, 9, 13, 64), (2, 32, 25, 100, 64), (3, 64, 12, 50, 128), (1, 48, 37, 19, 192),
+                                 (2, 16, 2, 2, 64)]:
         x, w, b = torch.randn(B, Cin, H, W), torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5), torch.randn(Cout)
         want = O.conv_block(x, w, b)
         y = torch.empty(B, Cout, H // 2, W // 2, device=DEV)
