@@ -41,6 +41,21 @@ __device__ __forceinline__ void split3(float x, bf16_t& s0, bf16_t& s1, bf16_t& 
     s2 = f2bf(r1 - bf2f(s1));
 }
 
+// two values at once: v_cvt_pk_bf16_f32 (round to nearest even, as f2bf) packs the pair into one dword
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& s0, unsigned& s1, unsigned& s2) {
+    f32v2 v = {x0, x1};
+    bf16v2 b0 = __builtin_convertvector(v, bf16v2);
+    v -= __builtin_convertvector(b0, f32v2);
+    bf16v2 b1 = __builtin_convertvector(v, bf16v2);
+    v -= __builtin_convertvector(b1, f32v2);
+    bf16v2 b2 = __builtin_convertvector(v, bf16v2);
+    s0 = *reinterpret_cast<unsigned*>(&b0);
+    s1 = *reinterpret_cast<unsigned*>(&b1);
+    s2 = *reinterpret_cast<unsigned*>(&b2);
+}
+
 constexpr int CH = 16;                        // input channels per chunk (= one MFMA k-step per tap)
 constexpr int CO_BLK = 64;
 constexpr int W_SLAB_U4 = 9 * 3 * 2 * CO_BLK;   // 16-byte pieces of one weight chunk slab (55,296 B)
@@ -154,18 +169,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             if (loff[e] >= 0) {
-                bf16_t s[3][8];
+                unsigned s[3][4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) split3(xin[e][j], s[0][j], s[1][j], s[2][j]);
+                for (int j = 0; j < 4; ++j) split3_pair(xin[e][2 * j], xin[e][2 * j + 1], s[0][j], s[1][j], s[2][j]);
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) {
-                    uint4 t;
-                    t.x = (unsigned)s[sp][0] | ((unsigned)s[sp][1] << 16);
-                    t.y = (unsigned)s[sp][2] | ((unsigned)s[sp][3] << 16);
-                    t.z = (unsigned)s[sp][4] | ((unsigned)s[sp][5] << 16);
-                    t.w = (unsigned)s[sp][6] | ((unsigned)s[sp][7] << 16);
-                    in_w[loff[e] + sp * SPLIT_U4] = t;
-                }
+                for (int sp = 0; sp < 3; ++sp)
+                    in_w[loff[e] + sp * SPLIT_U4] = make_uint4(s[sp][0], s[sp][1], s[sp][2], s[sp][3]);
             }
         }
     };

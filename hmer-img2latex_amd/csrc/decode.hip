@@ -17,6 +17,7 @@
 // so a step is: gates = P[tok] + Genc + h @ W_hh^T (a k-ordered fmaf chain per gate),
 // LSTM pointwise, logits = h' @ W_out^T + b, first-index argmax by wave shuffles.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -27,9 +28,14 @@ constexpr int NT = 256;        // threads per workgroup
 constexpr int VCHUNK = 2 * NT;  // vocab columns per projection pass
 
 struct Layout {
-    size_t P, Genc, WhhT[MAXL], WihT[MAXL], biasP[MAXL], WoutT, boutP, gemm_ws, total;
-    int Vp;
+    size_t P, Genc, WhhT[MAXL], WihT[MAXL], biasP[MAXL], WoutT, boutP, gemm_ws, xchg, xchg_bytes, total;
+    int Vp, n_groups;
 };
+
+// grouped decode (decode_group.inc.h): exchange granules [groups padded to 8][2][4][264] x 8 B + a status block
+constexpr size_t GROUP_XCHG_PER_GROUP = (size_t)2 * 4 * 264 * 8;
+constexpr size_t GROUP_STATUS_BYTES = 2048;
+inline bool group_shape_ok(int V, int H, int L) { return L == 1 && H == 256 && V <= 512; }
 
 Layout make_layout(int rows, int V, int E, int H, int L) {
     Layout o{};
@@ -47,6 +53,12 @@ Layout make_layout(int rows, int V, int E, int H, int L) {
     size_t g1 = i2l_gemm_workspace_bytes(V, 4 * H, E), g2 = i2l_gemm_workspace_bytes(rows, 4 * H, E);
     o.gemm_ws = off;
     off += i2l_align(g1 > g2 ? g1 : g2);
+    if (group_shape_ok(V, H, L)) {
+        o.n_groups = i2l_cdiv(rows, 4);
+        o.xchg = off;
+        o.xchg_bytes = GROUP_STATUS_BYTES + (size_t)i2l_cdiv(o.n_groups, 8) * 8 * GROUP_XCHG_PER_GROUP;
+        off += i2l_align(o.xchg_bytes);
+    }
     o.total = off;
     return o;
 }
@@ -376,6 +388,8 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned row
     z = z ^ (z >> 31);
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
+
+#include "decode_group.inc.h"
 
 // KR / KL > 0 (fast path for R == 1, L == 1, H <= 256: thread j owns hidden unit j for the whole loop):
 // rows [0,KR) of WhhT stay in the thread's registers and rows [KR,KR+KL) in LDS for all steps, so only
@@ -1021,6 +1035,26 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
     p.select = select; p.stop = stop; p.end_id = end_id;
     p.top_k = top_k; p.top_p = top_p; p.seed = seed; p.probs = probs_out;
 
+    // grouped kernel: 4 workgroups share 4 rows, weights fully on chip (decode_group.inc.h)
+    static const bool group_off = getenv("I2L_DECODE_GROUP") != nullptr && atoi(getenv("I2L_DECODE_GROUP")) == 0;
+    if (!group_off && rows_per_wg == 0 && lo.xchg_bytes && select == I2L_SELECT_LOGITS && !h0 && !h_out && !c_out &&
+        steps >= 8 && steps < (1 << 30)) {
+        GroupParams gp{};
+        gp.w = p.w; gp.B = rows; gp.T = steps; gp.n_groups = lo.n_groups;
+        gp.tok0 = tok0; gp.forced = forced; gp.ids = ids_out; gp.logits = logits_out;
+        gp.temperature = temperature; gp.use_temp = p.use_temp; gp.stop = stop; gp.end_id = end_id;
+        char* xb = const_cast<char*>(base) + lo.xchg;           // scratch region of the workspace
+        gp.status = reinterpret_cast<unsigned*>(xb);
+        gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
+        hipStream_t gs = i2l_s(stream);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP_LDS) == hipSuccess) {
+            if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
+            hipLaunchKernelGGL(decode_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(NT), GRP_LDS, gs, gp);
+            I2L_CHECK_LAUNCH();
+            return I2L_OK;
+        }
+    }
     // rows per workgroup: fill the 256 CUs first, then stack rows (weights are streamed once per workgroup per step)
     int R = rows <= 256 ? 1 : (rows <= 512 ? 2 : 4);
     if (rows_per_wg > 0) R = rows_per_wg;
@@ -1120,3 +1154,9 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
         default: return I2L_ERR_UNSUPPORTED;
     }
 }
+
+#ifdef I2L_GROUP_STAMPS
+extern "C" size_t i2l_debug_group_status_offset(int rows, int vocab, int embed, int hidden, int layers) {
+    return make_layout(rows, vocab, embed, hidden, layers).xchg;
+}
+#endif

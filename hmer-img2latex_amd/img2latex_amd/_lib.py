@@ -114,6 +114,17 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"img2latex_amd: {what} failed: {lib().i2l_error_string(rc).decode()} (code {rc})")
 
 
+def check_ids(ids_host: torch.Tensor) -> torch.Tensor:
+    """The grouped decode kernel marks every id of a row with -3 when one of its bounded inter-workgroup
+    polls expired (decode_group.inc.h); surface that as an error instead of returning garbage."""
+    # a timed-out workgroup fills its whole row, so the first column tells (and a pinned buffer is slow to scan)
+    first = ids_host[:, 0] if ids_host.dim() == 2 else ids_host
+    if first.numel() and bool((first == -3).any()):
+        raise RuntimeError("img2latex_amd: grouped decode timed out waiting for a peer workgroup "
+                           "(GPU oversubscribed?); set I2L_DECODE_GROUP=0 to use the row-per-workgroup kernel")
+    return ids_host
+
+
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 

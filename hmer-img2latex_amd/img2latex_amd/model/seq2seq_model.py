@@ -87,7 +87,7 @@ class Seq2SeqModel(nn.Module):
         rows independently, so that step is located in the ids afterwards."""
         B = encoder_output.shape[0]
         ids, _ = self.greedy_ids(encoder_output, start_token_id, end_token_id, max_length, temperature)
-        ids = ids.cpu()                                           # the ONE device->host sync of the search
+        ids = _lib.check_ids(ids.cpu())                           # the ONE device->host sync of the search
         all_end = (ids == end_token_id).all(dim=0)
         steps = int(all_end.nonzero()[0]) + 1 if bool(all_end.any()) else max_length
         rows = ids[:, :steps].tolist()

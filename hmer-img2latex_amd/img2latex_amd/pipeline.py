@@ -88,7 +88,7 @@ class GreedyPipeline:
         if self._lent is not None:
             self._free.append(self._lent)
         self._lent = host
-        return host
+        return _lib.check_ids(host)
 
     def drain(self) -> List[torch.Tensor]:
         out = []

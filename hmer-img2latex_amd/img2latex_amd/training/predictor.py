@@ -123,7 +123,7 @@ class Predictor:
                                                select=_lib.SELECT_SOFTMAX)
         end, start = self.tokenizer.end_token_id, self.tokenizer.start_token_id
         out = []
-        for row in ids.cpu().tolist():
+        for row in _lib.check_ids(ids.cpu()).tolist():
             row = [t for t in row if t >= 0]
             out.append([start] + (row[: row.index(end)] if end in row else row))
         return out
