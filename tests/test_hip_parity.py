@@ -475,3 +475,36 @@ def test_rows_per_workgroup_does_not_change_results():
             got, _ = m.greedy_ids(enc, START, END, 60, rows_per_workgroup=r)
             assert torch.equal(got, base), r
     assert np.array_equal(base.cpu().numpy(), d["ids"][:70, 1:61])
+
+
+@pytest.mark.parametrize("rows", [1, 3, 4, 70, 256])
+def test_grouped_decode_matches_row_per_workgroup_kernel(rows):
+    """The grouped kernel (4 workgroups x 4 rows, weights on chip, in-launch exchanges; csrc/decode_group.inc.h) against
+    the row-per-workgroup kernel on the same inputs: full and ragged groups, free-running ids (equal wherever the
+    top-2 margin is not a rounding tie), teacher-forced logits, and the sticky stop rule."""
+    d, cfg, sd_kw = load("primary_cfg2_clock")
+    m, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    x = torch.from_numpy(synth.make_images(256, cfg, seed=77)[:rows]).to(DEV)
+    T = 40
+    with torch.no_grad():
+        enc = m.encoder(x)
+        tok0 = torch.full((rows,), START, dtype=torch.int32, device=DEV)
+        # teacher forcing: identical inputs at every step -> logits comparable step by step
+        forced = torch.from_numpy(synth.randint(5, "forced", (rows, T), 4, cfg["vocab_size"]).astype(np.int32)).to(DEV)
+        _, lg_old, _ = m.decoder.run_steps(enc, T, tok0, forced=forced, want_logits=True, rows_per_workgroup=1)
+        ids_grp, lg_grp, _ = m.decoder.run_steps(enc, T, tok0, forced=forced, want_logits=True)
+        close(lg_grp.cpu().numpy(), lg_old.cpu().numpy(), 2e-5)
+        assert np.array_equal(ids_grp.cpu().numpy(), lg_grp.argmax(-1).cpu().numpy())
+        # free running, sticky stop: same ids except after a near-tie (then the sequences legitimately diverge)
+        ids_old, lg_free, _ = m.decoder.run_steps(enc, T, tok0, stop=_lib.STOP_STICKY, end_id=END, want_logits=True,
+                                                  rows_per_workgroup=1)
+        ids_new, _, _ = m.decoder.run_steps(enc, T, tok0, stop=_lib.STOP_STICKY, end_id=END)
+    a, b = ids_old.cpu().numpy(), ids_new.cpu().numpy()
+    top2 = torch.topk(lg_free, 2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1]).cpu().numpy()
+    for r in range(rows):
+        diff = np.nonzero(a[r] != b[r])[0]
+        if diff.size:
+            t0 = int(diff[0])
+            assert margin[r, t0] < 2e-4, (r, t0, margin[r, t0])
+    assert (a == b).mean() > 0.97
