@@ -32,8 +32,8 @@ struct Layout {
     int Vp, n_groups;
 };
 
-// grouped decode (decode_group.inc.h): exchange granules [groups padded to 8][2][4][264] x 8 B + a status block
-constexpr size_t GROUP_XCHG_PER_GROUP = (size_t)2 * 4 * 264 * 8;
+// grouped decode (decode_group.inc.h): exchange granules [groups padded to 8][2][4][288] x 8 B + a status block
+constexpr size_t GROUP_XCHG_PER_GROUP = (size_t)2 * 4 * 288 * 8;
 constexpr size_t GROUP_STATUS_BYTES = 2048;
 inline bool group_shape_ok(int V, int H, int L) { return L == 1 && H == 256 && V <= 512; }
 
@@ -1050,7 +1050,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP_LDS) == hipSuccess) {
             if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
-            hipLaunchKernelGGL(decode_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(NT), GRP_LDS, gs, gp);
+            hipLaunchKernelGGL(decode_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(GNT), GRP_LDS, gs, gp);
             I2L_CHECK_LAUNCH();
             return I2L_OK;
         }

@@ -5,6 +5,8 @@
 // each keeps one QUARTER of the weights on chip for the whole loop, so nothing is streamed:
 //     member m holds  WhhT[:, gate columns of hidden units 64m..64m+63]   256 x 256 floats in registers
 //                     WoutT[:, vocabulary columns 128m..128m+127]          256 x 128 floats in LDS
+// with 512 threads per workgroup (two waves per SIMD: one wave's LDS / DPP / transcendental latencies are the
+// other's issue slots, and 128 weights per thread stay in architectural registers).
 // Per step member m computes, for all 4 rows, the gates / LSTM cell of ITS 64 hidden units and the logits of ITS 128
 // vocabulary columns; both need the full h of the group, so a step has two small exchanges inside the group:
 //     1. every member publishes its 64 x 4 new h values and reads the other three quarters;
@@ -28,11 +30,12 @@ typedef unsigned long long u64_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int GQ = 4;                    // workgroups (= rows) per group
+constexpr int GNT = 512;                 // threads per workgroup
 constexpr int GRAN_H = 256;              // h granules per member and step: [unit 64][row 4]
-constexpr int GRAN = GRAN_H + 8;         // + 4 candidate granules (one per row) + 4 unused
-constexpr int GRP_HS = 65 * 4;           // floats per quarter of h_s (65: the 4 quarters sit on disjoint banks)
-constexpr int GRP_WLD = 144;             // row stride of wout_s: rows k, k+1, k+2, k+3 sit on disjoint banks
-constexpr size_t GRP_LDS = (size_t)(256 * GRP_WLD + 4 * GRP_HS + 2 * 128 + 8) * sizeof(float);
+constexpr int GRAN_C = GRAN_H;           // 4 candidate granules (one per row), a 128-byte line of their own
+constexpr int GRAN_X = GRAN_H + 16;      // 1 placement granule (XCC id), a line of its own
+constexpr int GRAN = GRAN_H + 32;
+constexpr size_t GRP_LDS = (size_t)(256 * 128 + 256 * 4) * sizeof(float) + (size_t)2 * 4 * 32 * 8 + 8 * sizeof(int);
 constexpr long long GRP_TIMEOUT_TICKS = 300000000ll;   // 3 s of the 100 MHz wall clock
 
 struct GroupParams {
@@ -48,22 +51,31 @@ struct GroupParams {
     unsigned* status;     // [0] != 0: a poll timed out
 };
 
-__device__ __forceinline__ void store_granule(u64_t* g, unsigned epoch, float v) {
-    __hip_atomic_store(g, ((u64_t)epoch << 32) | (u64_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// local == false: sc1 store (write-through to memory, seen from every XCD).  local == true (all four members were
+// found on ONE XCD): sc0 store, the line stays in that XCD's L2 where the peers' sc1 loads (L1 bypassed) find it --
+// an L2 round trip instead of a memory one.
+__device__ __forceinline__ void store_granule(u64_t* g, u64_t v, bool local) {
+    if (local) __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ u64_t granule(unsigned tag, float v) { return ((u64_t)tag << 32) | (u64_t)__float_as_uint(v); }
 __device__ __forceinline__ u64_t load_granule(const u64_t* g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float dpp_quad_sum(float v) {
-    // all four lanes of a quad end with ((q0+q1)+(q2+q3)) -- the same bits in every lane
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    return v;
+// DPP controls: quad_perm [1,0,3,2] (lane ^ 1), quad_perm [2,3,0,1] (lane ^ 2), row_half_mirror (lane -> 7 - lane
+// within 8), row_ror:n (rotate within 16), row_shl:n (lane reads lane + n)
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HMIRROR = 0x141, DPP_ROR4 = 0x124, DPP_ROR8 = 0x128,
+              DPP_SHL4 = 0x104, DPP_SHL8 = 0x108;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float dpp_oct_sum(float v) {      // 8 consecutive lanes; the same bits in all of them
-    v = dpp_quad_sum(v);
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    return v;
+// One level of a reduce-scatter between a lane and its DPP partner: the pair holds partial sums of the same two
+// values (a, b); the lane with sel == false keeps a, its partner keeps b, each adds the other's partial.
+template <int CTRL>
+__device__ __forceinline__ float rs_level(float a, float b, bool sel) {
+    const float keep = sel ? b : a, send = sel ? a : b;
+    return keep + dpp_f<CTRL>(send);
 }
 __device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
 // (value, index) as one unsigned 64-bit key whose order is "larger value first, then smaller index": arg max with
@@ -94,13 +106,21 @@ __device__ __forceinline__ void pkfma_lo(f32x2& acc, f32x2 wpair, f32x2 h) {
 __device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 wpair, f32x2 h) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(wpair), "v"(h));
 }
+// acc[4 values][2 row pairs] += w4 (4 values: gates or columns) x h4 (4 rows)
+__device__ __forceinline__ void fma_4x4(f32x2 (&acc)[4][2], f32x2 w01, f32x2 w23, float4 hv) {
+    const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+    pkfma_lo(acc[0][0], w01, h01); pkfma_lo(acc[0][1], w01, h23);
+    pkfma_hi(acc[1][0], w01, h01); pkfma_hi(acc[1][1], w01, h23);
+    pkfma_lo(acc[2][0], w23, h01); pkfma_lo(acc[2][1], w23, h23);
+    pkfma_hi(acc[3][0], w23, h01); pkfma_hi(acc[3][1], w23, h23);
+}
 
-__global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
+__global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wout_s = smem;                                   // [256][144] this member's 128 columns of WoutT
-    float* h_s = wout_s + 256 * GRP_WLD;                    // [4][65][4] full h of the last step: [quarter][unit][row]
-    u64_t* redk = reinterpret_cast<u64_t*>(h_s + 4 * GRP_HS);   // [2][4 rows][16 = wave x lane row] arg-max keys
-    int* tok_s = reinterpret_cast<int*>(redk + 128);       // [0..3] tokens of the last step (-1: timed out), [4] h poll timed out                                 // [4] tokens, [4] = failure flag
+    float4* wout_s4 = reinterpret_cast<float4*>(smem);      // [16 j][512 threads]: WoutT[16j + ks][128m + 4cq ..+3]
+    float* h_s = smem + 256 * 128;                          // [256 k][4 rows]  full h of the last step
+    u64_t* redk = reinterpret_cast<u64_t*>(h_s + 256 * 4);  // [2][4 rows][32 column groups] arg-max keys
+    int* tok_s = reinterpret_cast<int*>(redk + 2 * 4 * 32); // [0..3] tokens of the last step (-1: timed out), [4] h poll timed out
 
     const StepWeights& w = p.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,27 +129,28 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
     if (group >= p.n_groups) return;
     const int B = p.B, T = p.T, V = w.V;
     const int row0 = group * GQ;
-    const int ul = tid >> 2, kq = tid & 3;                  // gates: hidden unit 64m+ul, k in [64kq, 64kq+64); cell: row kq
+    // gates: hidden unit 64m + ul, k = ke (mod 8) -> 32 k, 4 gates x 4 rows;  cell: lanes ke < 4 own (unit, row ke)
+    const int ul = tid >> 3, ke = tid & 7;
     const int unit = 64 * m + ul;
-    const int cq = tid >> 3, ke = tid & 7;                  // logits: columns 128m + 4cq.., k = ke (mod 8); row ke & 3
+    // logits: columns 128m + 4cq ..+3, k = ks (mod 16) -> 16 k, 4 columns x 4 rows; afterwards the lane owns ONE logit
+    const int cq = tid >> 4, ks = tid & 15;
+    const int l_row = ks & 3, l_col = ((ks >> 2) & 1) * 2 + (ks >> 3);
+    const int l_v = 128 * m + 4 * cq + l_col;
     constexpr int G = 1024;                                 // 4 * H
 
-    f32x2 wreg[64][2];                                      // WhhT[64kq + kk][4 unit .. +3] as (i,f), (g,o)
+    f32x2 wreg[32][2];                                      // WhhT[8j + ke][4 unit .. +3] as (i,f), (g,o)
 #pragma unroll
-    for (int kk = 0; kk < 64; ++kk) {
-        const float4 t4 = *reinterpret_cast<const float4*>(w.WhhT[0] + (size_t)(64 * kq + kk) * G + 4 * unit);
-        wreg[kk][0] = f32x2{t4.x, t4.y};
-        wreg[kk][1] = f32x2{t4.z, t4.w};
+    for (int j = 0; j < 32; ++j) {
+        const float4 t4 = *reinterpret_cast<const float4*>(w.WhhT[0] + (size_t)(8 * j + ke) * G + 4 * unit);
+        wreg[j][0] = f32x2{t4.x, t4.y};
+        wreg[j][1] = f32x2{t4.z, t4.w};
     }
-    for (int idx = tid; idx < 256 * 32; idx += NT) {
-        const int k = idx >> 5, c4 = idx & 31;
-        *reinterpret_cast<float4*>(wout_s + k * GRP_WLD + 4 * c4) =
-            *reinterpret_cast<const float4*>(w.WoutT + (size_t)k * 512 + 128 * m + 4 * c4);
-    }
-    for (int idx = tid; idx < 4 * GRP_HS; idx += NT) h_s[idx] = 0.f;
-    if (tid < 8) tok_s[tid] = 0;
-    const float4 genc = *reinterpret_cast<const float4*>(w.Genc + (size_t)min(row0 + kq, B - 1) * G + 4 * unit);
-    const float2 bo = *reinterpret_cast<const float2*>(w.boutP + 128 * m + 4 * cq + 2 * (ke >> 2));
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        wout_s4[j * GNT + tid] = *reinterpret_cast<const float4*>(w.WoutT + (size_t)(16 * j + ks) * 512 + 128 * m + 4 * cq);
+    for (int idx = tid; idx < 256 * 4; idx += GNT) h_s[idx] = 0.f;
+    const float4 genc = *reinterpret_cast<const float4*>(w.Genc + (size_t)min(row0 + (ke & 3), B - 1) * G + 4 * unit);
+    const float l_bias = w.boutP[l_v];
     float c_own = 0.f, h_own = 0.f;
     int tok[GQ];
     unsigned fin = 0;                                       // bit r: row r has emitted END (or does not exist)
@@ -141,9 +162,37 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
     u64_t* xg = p.xchg + (size_t)group * 2 * GQ * GRAN;
     const bool own_row = row0 + m < B;                      // this member writes the ids of row m
     int32_t* ids_row = (p.ids && own_row) ? p.ids + (size_t)(row0 + m) * T : nullptr;
-    float* lrow = (p.logits && row0 + (ke & 3) < B) ? p.logits + (size_t)(row0 + (ke & 3)) * T * V : nullptr;
+    float* lrow = (p.logits && row0 + l_row < B && l_v < V) ? p.logits + (size_t)(row0 + l_row) * T * V + l_v : nullptr;
     u64_t cand_k = 0;                                       // wave 0, lanes 0..3: this member's candidate of row = lane
+    // Placement: are the four members on one XCD?  Each publishes its XCC id (sc1, seen from anywhere); equal ids
+    // switch the granule stores to the L2-local flavour.  Measured, never assumed: correctness does not depend on it
+    // (if a member times out here it fails the launch like any other poll).
+    if (wave == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xFu;
+        if (lane == 0) store_granule(xg + (size_t)m * GRAN + GRAN_X, granule(0xC0DEu, __uint_as_float(xcc)), false);
+        const int pq = (lane & 3) + ((lane & 3) >= m ? 1 : 0);
+        u64_t pv = 0;
+        bool bad = false;
+        long long t_start = 0;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            if (lane < 3) { pv = load_granule(xg + (size_t)pq * GRAN + GRAN_X); ok = (unsigned)(pv >> 32) == 0xC0DEu; }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0) {
+                const long long now = (long long)wall_clock64();
+                if (t_start == 0) t_start = now;
+                else if (now - t_start > GRP_TIMEOUT_TICKS) { bad = true; break; }
+            }
+        }
+        const bool all_same = __all(lane >= 3 || (unsigned)pv == xcc);
+        if (lane == 0) { tok_s[5] = (all_same && !bad) ? 1 : 0; tok_s[4] = bad ? 1 : 0; }
+    }
     __syncthreads();
+    const bool local = tok_s[5] != 0;
 
     int t = 0;
     bool failed = false;
@@ -155,40 +204,32 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
 #define I2L_STAMP(i) do { } while (0)
 #endif
     for (;; ++t) {
-        // ---- A. token-independent part of the gates of step t: sum_k h[k] Whh[k][.]; thread = (unit, k-quarter)
+        // ---- A. token-independent part of the gates of step t: sum_k h[k] Whh[k][.]
         f32x2 acc[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) { acc[g][0] = splat2(0.f); acc[g][1] = splat2(0.f); }
         u64_t gv = 0;                                       // wave 0, lanes 0..11: candidate granule (peer, row)
         const int c_qi = lane >> 2;
         const u64_t* cand_src = xg + (size_t)((t - 1) & 1) * GQ * GRAN + (size_t)(c_qi + (c_qi >= m ? 1 : 0)) * GRAN +
-                                GRAN_H + (lane & 3);
+                                GRAN_C + (lane & 3);
         const bool c_poll = wave == 0 && lane < 12 && t > 0;
         if (t > 0 && t < T) {
-            // h is read 4 k ahead of its use (two register sets): the LDS latency hides behind 32 FMAs
-            const float4* hq4 = reinterpret_cast<const float4*>(h_s + kq * GRP_HS);
+            // h is read 4 k ahead of its use (two register sets)
+            const float4* hq4 = reinterpret_cast<const float4*>(h_s) + ke;
             float4 hb[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hb[0][i] = hq4[i];
+            for (int i = 0; i < 4; ++i) hb[0][i] = hq4[8 * i];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                if (b + 1 < 16) {
+            for (int b = 0; b < 8; ++b) {
+                if (b + 1 < 8) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hb[(b + 1) & 1][i] = hq4[(b + 1) * 4 + i];
+                    for (int i = 0; i < 4; ++i) hb[(b + 1) & 1][i] = hq4[8 * ((b + 1) * 4 + i)];
                 }
                 // the peers published their candidates about when this member did: fetch them mid-way, use them after
-                if (b == 9 && c_poll) gv = load_granule(cand_src);
+                if (b == 4 && c_poll) gv = load_granule(cand_src);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int kk = b * 4 + i;
-                    const float4 hv = hb[b & 1][i];
-                    const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
-                    pkfma_lo(acc[0][0], wreg[kk][0], h01); pkfma_lo(acc[0][1], wreg[kk][0], h23);
-                    pkfma_hi(acc[1][0], wreg[kk][0], h01); pkfma_hi(acc[1][1], wreg[kk][0], h23);
-                    pkfma_lo(acc[2][0], wreg[kk][1], h01); pkfma_lo(acc[2][1], wreg[kk][1], h23);
-                    pkfma_hi(acc[3][0], wreg[kk][1], h01); pkfma_hi(acc[3][1], wreg[kk][1], h23);
-                }
+                for (int i = 0; i < 4; ++i) fma_4x4(acc, wreg[b * 4 + i][0], wreg[b * 4 + i][1], hb[b & 1][i]);
             }
         } else if (c_poll) {
             gv = load_granule(cand_src);
@@ -212,18 +253,15 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
                     }
                     if (lane < 12) gv = load_granule(cand_src);
                 }
-                // lane r < 4 gathers the three peers' granules of row r (lanes r, r+4, r+8: row_shl 4 / 8)
+                // lane r < 4 gathers the three peers' granules of row r (lanes r, r+4, r+8); the members own disjoint
+                // index ranges, so the order of the max does not matter
                 const int g_lo = (int)(unsigned)gv, g_hi = (int)(unsigned)(gv >> 32);
-                const int p_lo[3] = {g_lo, __builtin_amdgcn_mov_dpp(g_lo, 0x104, 0xF, 0xF, true),
-                                     __builtin_amdgcn_mov_dpp(g_lo, 0x108, 0xF, 0xF, true)};
-                const int p_hi[3] = {g_hi, __builtin_amdgcn_mov_dpp(g_hi, 0x104, 0xF, 0xF, true),
-                                     __builtin_amdgcn_mov_dpp(g_hi, 0x108, 0xF, 0xF, true)};
-                // the members own disjoint index ranges, so the order of the max does not matter
-                u64_t best = cand_k;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) best = umax64(best, am_key(__int_as_float(p_lo[j]), p_hi[j] & 0xFFFF));
-                const int bi = am_idx(best);
-                if (lane < 4) tok_s[lane] = bad ? -1 : bi;
+                u64_t best = umax64(cand_k, am_key(__int_as_float(g_lo), g_hi & 0xFFFF));
+                best = umax64(best, am_key(__int_as_float(__builtin_amdgcn_mov_dpp(g_lo, DPP_SHL4, 0xF, 0xF, true)),
+                                           __builtin_amdgcn_mov_dpp(g_hi, DPP_SHL4, 0xF, 0xF, true) & 0xFFFF));
+                best = umax64(best, am_key(__int_as_float(__builtin_amdgcn_mov_dpp(g_lo, DPP_SHL8, 0xF, 0xF, true)),
+                                           __builtin_amdgcn_mov_dpp(g_hi, DPP_SHL8, 0xF, 0xF, true) & 0xFFFF));
+                if (lane < 4) tok_s[lane] = bad ? -1 : am_idx(best);
             }
             __syncthreads();
             const int4 tk4 = *reinterpret_cast<const int4*>(tok_s);
@@ -233,8 +271,7 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
             bool all_fin = true;
 #pragma unroll
             for (int r = 0; r < GQ; ++r) {
-                const int bi = tk[r];
-                const int sel = bi < V ? bi : 0;
+                const int sel = tk[r] < V ? tk[r] : 0;
                 const bool was_fin = (fin >> r) & 1u;
                 if (r == m && tid == 0 && ids_row) ids_row[t - 1] = (p.stop == I2L_STOP_STICKY && was_fin) ? -1 : sel;
                 tok[r] = sel;
@@ -248,41 +285,48 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
 #pragma unroll
             for (int r = 0; r < GQ; ++r) tok[r] = min(max(p.forced[(size_t)min(row0 + r, B - 1) * T + t], 0), V - 1);
         }
-        // ---- C. LSTM cell of (unit, row kq), publish the new h
+        // ---- C. fold the 8 k-slices (reduce-scatter: 16 -> 8 -> 4 -> 2 values per lane), LSTM cell of (unit, row ke)
         const unsigned epoch = (unsigned)t + 1u;
         u64_t* slot = xg + (size_t)(t & 1) * GQ * GRAN;
         {
-            const int mytok = kq == 0 ? tok[0] : (kq == 1 ? tok[1] : (kq == 2 ? tok[2] : tok[3]));
+            const int kr = ke & 3;
+            const int mytok = kr == 0 ? tok[0] : (kr == 1 ? tok[1] : (kr == 2 ? tok[2] : tok[3]));
             const float4 pv = *reinterpret_cast<const float4*>(w.P + (size_t)mytok * G + 4 * unit);
-            float gs[4];
+            const bool b0 = ke & 1, b1 = ke & 2, b2 = ke & 4;
+            float z[2];                                     // lanes ke < 4: gates (i, f); ke >= 4: (g, o); row ke & 3
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float s0 = dpp_quad_sum(acc[g][0].x), s1 = dpp_quad_sum(acc[g][0].y);
-                const float s2 = dpp_quad_sum(acc[g][1].x), s3 = dpp_quad_sum(acc[g][1].y);
-                gs[g] = kq == 0 ? s0 : (kq == 1 ? s1 : (kq == 2 ? s2 : s3));
+            for (int e = 0; e < 2; ++e) {
+                float wv[2];
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const float ux = rs_level<DPP_HMIRROR>(acc[e][rp].x, acc[2 + e][rp].x, b2);
+                    const float uy = rs_level<DPP_HMIRROR>(acc[e][rp].y, acc[2 + e][rp].y, b2);
+                    wv[rp] = rs_level<DPP_XOR1>(ux, uy, b0);
+                }
+                z[e] = rs_level<DPP_XOR2>(wv[0], wv[1], b1);
             }
-            const float xi = (gs[0] + genc.x) + pv.x, xf = (gs[1] + genc.y) + pv.y;
-            const float xc = (gs[2] + genc.z) + pv.z, xo = (gs[3] + genc.w) + pv.w;
+            const float g2 = dpp_f<DPP_SHL4>(z[0]), g3 = dpp_f<DPP_SHL4>(z[1]);      // (g, o) from lane ke + 4
+            const float xi = (z[0] + genc.x) + pv.x, xf = (z[1] + genc.y) + pv.y;
+            const float xc = (g2 + genc.z) + pv.z, xo = (g3 + genc.w) + pv.w;
             const float ig = sigmoidf_(xi), fg = sigmoidf_(xf), gg = tanhf(xc), og = sigmoidf_(xo);
             c_own = fg * c_own + ig * gg;
             h_own = og * tanhf(c_own);
         }
-        store_granule(slot + (size_t)m * GRAN + tid, epoch, h_own);
+        if (ke < 4) store_granule(slot + (size_t)m * GRAN + ul * 4 + ke, granule(epoch, h_own), local);
         I2L_STAMP(2);
-        // ---- D. the other three quarters of h
-        u64_t gr[3];
+        // ---- D. the other three quarters of h: threads 0..255 fetch peers 0 and 1, threads 256..511 peer 2
+        u64_t gr[2];
         {
+            const int gi = tid & 255;
+            const int qa = tid < 256 ? 0 : 2;
+            const u64_t* pa_ = slot + (size_t)(qa + (qa >= m ? 1 : 0)) * GRAN + gi;
+            const u64_t* pb_ = slot + (size_t)(1 + (1 >= m ? 1 : 0)) * GRAN + gi;
             long long t_start = 0;
             unsigned spins = 0;
             for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int qi = 0; qi < 3; ++qi) {
-                    const int q = qi + (qi >= m ? 1 : 0);
-                    gr[qi] = load_granule(slot + (size_t)q * GRAN + tid);
-                    ok = ok && (unsigned)(gr[qi] >> 32) == epoch;
-                }
-                if (ok) break;
+                gr[0] = load_granule(pa_);
+                gr[1] = tid < 256 ? load_granule(pb_) : gr[0];
+                if ((unsigned)(gr[0] >> 32) == epoch && (unsigned)(gr[1] >> 32) == epoch) break;
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 255u) == 0) {
                     const long long now = (long long)wall_clock64();
@@ -290,34 +334,28 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
                     else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
                 }
             }
+            I2L_STAMP(3);
+            // every thread passed the barrier of B (t > 0) after its reads of h_s, so h_s may be rewritten right away
+            h_s[(qa + (qa >= m ? 1 : 0)) * 256 + gi] = __uint_as_float((unsigned)gr[0]);
+            if (tid < 256) h_s[(1 + (1 >= m ? 1 : 0)) * 256 + gi] = __uint_as_float((unsigned)gr[1]);
         }
-        I2L_STAMP(3);
-        // every thread passed the barrier of B (t > 0) after its reads of h_s, so h_s may be rewritten right away
-#pragma unroll
-        for (int qi = 0; qi < 3; ++qi) {
-            const int q = qi + (qi >= m ? 1 : 0);
-            h_s[q * GRP_HS + tid] = __uint_as_float((unsigned)gr[qi]);
-        }
-        h_s[m * GRP_HS + tid] = h_own;
+        if (ke < 4) h_s[m * 256 + ul * 4 + ke] = h_own;
         if (failed) { tok_s[4] = 1; failed = false; }      // a timed-out poll is reported at the next B (all threads see it)
         __syncthreads();
         I2L_STAMP(4);
 
-        // ---- E. logits of this member's 128 columns: thread = (4 columns 4cq.., k = ke mod 8), 4 rows -> 16 sums
-        f32x2 pa[4][2];                                     // [column][row pair]
+        // ---- E. logits of this member's 128 columns: thread = (4 columns, k = ks mod 16), 4 rows -> 16 sums
+        f32x2 pa[4][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { pa[c][0] = splat2(0.f); pa[c][1] = splat2(0.f); }
         {
-            f32x2 wb[2][4][2];
-            float4 hb[2][4];
+            const float4* hq4 = reinterpret_cast<const float4*>(h_s) + ks;
+            float4 wb[2][2], hb[2][2];
             auto fetch = [&](int set, int b) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = 8 * (b * 4 + i) + ke;
-                    const float4 w4 = *reinterpret_cast<const float4*>(wout_s + k * GRP_WLD + 4 * cq);
-                    wb[set][i][0] = f32x2{w4.x, w4.y};
-                    wb[set][i][1] = f32x2{w4.z, w4.w};
-                    hb[set][i] = *reinterpret_cast<const float4*>(h_s + (k >> 6) * GRP_HS + (k & 63) * 4);
+                for (int i = 0; i < 2; ++i) {
+                    wb[set][i] = wout_s4[(b * 2 + i) * GNT + tid];
+                    hb[set][i] = hq4[16 * (b * 2 + i)];
                 }
             };
             fetch(0, 0);
@@ -326,56 +364,52 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
                 if (b + 1 < 8) fetch((b + 1) & 1, b + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 hv = hb[b & 1][i];
-                    const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
-                    pkfma_lo(pa[0][0], wb[b & 1][i][0], h01); pkfma_lo(pa[0][1], wb[b & 1][i][0], h23);
-                    pkfma_hi(pa[1][0], wb[b & 1][i][0], h01); pkfma_hi(pa[1][1], wb[b & 1][i][0], h23);
-                    pkfma_lo(pa[2][0], wb[b & 1][i][1], h01); pkfma_lo(pa[2][1], wb[b & 1][i][1], h23);
-                    pkfma_hi(pa[3][0], wb[b & 1][i][1], h01); pkfma_hi(pa[3][1], wb[b & 1][i][1], h23);
+                for (int i = 0; i < 2; ++i) {
+                    const float4 w4 = wb[b & 1][i];
+                    fma_4x4(pa, f32x2{w4.x, w4.y}, f32x2{w4.z, w4.w}, hb[b & 1][i]);
                 }
             }
         }
         I2L_STAMP(5);
-        // the 8 lanes of a (4-column) group fold their k-slices; lane ke then owns row ke & 3, columns 2 (ke >> 2) + {0,1}
-        float lv[2];
+        // fold the 16 k-slices: 16 -> 8 -> 4 -> 2 -> 1; the lane ends with the logit of (column l_col, row l_row)
+        float lv;
         {
-            float sm[4][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                sm[c][0] = dpp_oct_sum(pa[c][0].x); sm[c][1] = dpp_oct_sum(pa[c][0].y);
-                sm[c][2] = dpp_oct_sum(pa[c][1].x); sm[c][3] = dpp_oct_sum(pa[c][1].y);
-            }
-            const int rr = ke & 3;
+            const bool b0 = ks & 1, b1 = ks & 2, b2 = ks & 4, b3 = ks & 8;
+            float z[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float lo = rr == 0 ? sm[e][0] : (rr == 1 ? sm[e][1] : (rr == 2 ? sm[e][2] : sm[e][3]));
-                const float hi = rr == 0 ? sm[2 + e][0] : (rr == 1 ? sm[2 + e][1] : (rr == 2 ? sm[2 + e][2] : sm[2 + e][3]));
-                lv[e] = ((ke >> 2) ? hi : lo) + (e == 0 ? bo.x : bo.y);
+                float wv[2];
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const float ux = rs_level<DPP_HMIRROR>(pa[e][rp].x, pa[2 + e][rp].x, b2);
+                    const float uy = rs_level<DPP_HMIRROR>(pa[e][rp].y, pa[2 + e][rp].y, b2);
+                    wv[rp] = rs_level<DPP_XOR1>(ux, uy, b0);
+                }
+                z[e] = rs_level<DPP_XOR2>(wv[0], wv[1], b1);
             }
+            lv = rs_level<DPP_ROR8>(z[0], z[1], b3) + l_bias;
         }
-        const int v0 = 128 * m + 4 * cq + 2 * (ke >> 2);
-        if (lrow) {
-            if (v0 < V) lrow[(size_t)t * V + v0] = lv[0];
-            if (v0 + 1 < V) lrow[(size_t)t * V + v0 + 1] = lv[1];
-        }
-        if (p.use_temp) { lv[0] = lv[0] / p.temperature; lv[1] = lv[1] / p.temperature; }
-        u64_t key = umax64(am_key(lv[0], v0), am_key(lv[1], v0 + 1));
-        key = umax64(key, dpp_u64<0x124>(key));             // row_ror:4, row_ror:8: the 4 lanes of a 16-lane row that
-        key = umax64(key, dpp_u64<0x128>(key));             // share (lane & 3) now hold the same key
-        const int par = (t & 1) * 64;
-        if ((lane & 15) < 4) redk[par + (lane & 3) * 16 + wave * 4 + (lane >> 4)] = key;
+        if (lrow) lrow[(size_t)t * V] = lv;
+        if (p.use_temp) lv = lv / p.temperature;
+        u64_t key = am_key(lv, l_v);
+        key = umax64(key, dpp_u64<DPP_ROR4>(key));          // the 4 lanes of a 16-lane row that share the row (lane & 3)
+        key = umax64(key, dpp_u64<DPP_ROR8>(key));
+        const int par = (t & 1) * 128;
+        if (ks < 4) redk[par + ks * 32 + cq] = key;
         __syncthreads();
-        if (wave == 0 && lane < 4) {
-            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(redk + par + lane * 16);
+        if (wave == 0) {
+            // lanes 0..15: row lane & 3, keys [8 (lane >> 2), +8) of its 32; then the 4 lanes of a row fold
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(redk + par + (lane & 3) * 32 + ((lane >> 2) & 3) * 8);
             u64_t best = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const ulonglong2 kk2 = src[j]; best = umax64(best, umax64(kk2.x, kk2.y)); }
-            cand_k = best;
-            __hip_atomic_store(slot + (size_t)m * GRAN + GRAN_H + lane,
-                               ((u64_t)((epoch << 16) | (unsigned)(am_idx(best) & 0xFFFF)) << 32) |
-                                   (u64_t)__float_as_uint(am_val(best)),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < 4; ++j) { const ulonglong2 k2 = src[j]; best = umax64(best, umax64(k2.x, k2.y)); }
+            best = umax64(best, dpp_u64<DPP_ROR4>(best));
+            best = umax64(best, dpp_u64<DPP_ROR8>(best));
+            if (lane < 4) {
+                cand_k = best;
+                store_granule(slot + (size_t)m * GRAN + GRAN_C + lane,
+                              granule((epoch << 16) | (unsigned)(am_idx(best) & 0xFFFF), am_val(best)), local);
+            }
         }
         I2L_STAMP(6);
     }
@@ -384,8 +418,8 @@ __global__ __launch_bounds__(NT) void decode_group_kernel(GroupParams p) {
 #endif
     if (failed) {
         if (tid == 0) atomicOr(p.status, 1u);
-        if (ids_row) for (int tt = tid; tt < T; tt += NT) ids_row[tt] = -3;
+        if (ids_row) for (int tt = tid; tt < T; tt += GNT) ids_row[tt] = -3;
         return;
     }
-    if (ids_row) for (int tt = t + tid; tt < T; tt += NT) ids_row[tt] = -1;   // steps never executed (sticky stop)
+    if (ids_row) for (int tt = t + tid; tt < T; tt += GNT) ids_row[tt] = -1;   // steps never executed (sticky stop)
 }

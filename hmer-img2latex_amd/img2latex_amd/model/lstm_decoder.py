@@ -103,10 +103,13 @@ class LSTMDecoder(nn.Module):
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def prepare(self, encoder_output: torch.Tensor, reuse_weight_images: bool = False):
+    def prepare(self, encoder_output: torch.Tensor, reuse_weight_images: bool = True):
         """Build the decode workspace for these encoder rows (i2l_decoder_prepare).
-        ``reuse_weight_images`` skips the weight re-layout when no parameter changed since
-        the last call (used by decode_step loops); the search entry points rebuild everything."""
+        The weight images (transposed / gate-interleaved matrices, the token table P) are rebuilt only
+        when a parameter changed since they were built -- (data_ptr, _version) of every parameter is
+        the cache key, the same contract as nn.LSTM's flattened weights; code that writes parameters
+        through raw pointers must bump the version (TrainStep.apply does).  ``reuse_weight_images=False``
+        forces the rebuild.  The image-dependent rows (Genc) are rebuilt on every call."""
         enc = _lib.require_gpu(encoder_output, "encoder_output")
         if enc.dim() != 2 or enc.shape[1] != self.embedding_dim:
             raise RuntimeError(f"encoder_output must be (B,{self.embedding_dim}), got {tuple(enc.shape)}")
@@ -137,7 +140,7 @@ class LSTMDecoder(nn.Module):
                   forced: Optional[torch.Tensor] = None, hidden: Optional[Hidden] = None,
                   temperature: float = 1.0, select: int = _lib.SELECT_LOGITS, stop: int = _lib.STOP_NONE,
                   end_id: int = -1, want_ids: bool = True, want_logits: bool = False,
-                  want_state: bool = False, reuse_weight_images: bool = False, rows_per_workgroup: int = 0):
+                  want_state: bool = False, reuse_weight_images: bool = True, rows_per_workgroup: int = 0):
         """prepare + one persistent i2l_greedy_decode launch.  Returns (ids, logits, (h, c))."""
         w, keep, enc = self.prepare(encoder_output, reuse_weight_images)
         rows, dev = enc.shape[0], enc.device

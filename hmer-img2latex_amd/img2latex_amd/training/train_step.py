@@ -98,6 +98,10 @@ class TrainStep:
             float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
             self.step_count, self._opt_ws.data_ptr(), self._opt_ws.numel(), self.stats.data_ptr(),
             _lib.stream_ptr()), "grad_clip_adam_step")
+        # the kernel wrote the parameters through raw pointers: tell autograd / the weight-image caches
+        # (LSTMDecoder.prepare, ResNetEncoder) that they changed
+        for p in self.model.parameters():
+            torch.autograd.graph.increment_version(p)
 
     def step(self, images: torch.Tensor, formulas: torch.Tensor) -> Dict[str, torch.Tensor]:
         """trainer.py:303-343 for one batch.  Returns device tensors (no sync): loss, total_norm, count."""
