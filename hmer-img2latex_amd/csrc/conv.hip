@@ -459,6 +459,8 @@ extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const 
                                            void* workspace, size_t workspace_bytes, i2l_stream_t stream) {
     if (!x || !w || !bias || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2) return I2L_ERR_ARG;
     // inference forward (no argmax wanted): split-bf16 matrix-core kernel where the channel counts allow
+    if (!argmax_out && i2l_conv_smallk_applicable(Cin, Cout))
+        return i2l_conv_smallk_run(x, w, bias, y, B, Cin, H, W, Cout, i2l_s(stream));
     if (!argmax_out && i2l_conv_bf16x3_applicable(Cin, Cout))
         return i2l_conv_bf16x3_run(x, w, bias, y, nullptr, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
     return run_conv(true, x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));

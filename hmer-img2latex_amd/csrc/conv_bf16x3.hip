@@ -285,6 +285,155 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// First conv block (Cin <= 3: K = 9 Cin <= 27): the whole K fits ONE or TWO bf16 MFMA k-steps, so the filter bank
+// (32 output channels x 32 k x 3 splits) lives in 24 registers per lane for the whole kernel and the A operand is an
+// im2col image built in LDS: thread P gathers the <= 27 taps of conv position P from a staged fp32 patch, splits
+// them and writes [split][k-step][k half][position][8 k] -- 16-byte pieces in position order, so a wave's
+// ds_read_b128 of one (split, k-step) is 1 KiB contiguous.  A workgroup walks the column tiles of an 8-row band
+// (8 x 32 positions per tile, 2 M-tiles per wave, 12 MFMAs per M-tile) with the next patch prefetched in registers.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv3x3_smallk_bf16x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+    int H, int W, int Cout, int Hp, int Wp, int tiles_x) {
+    constexpr int KT = CIN * 9, KS = (KT + 15) / 16, KP = KS * 16;
+    constexpr int PW = 48;                                   // patch row stride: rows r, r+1 on disjoint halves of the 32 banks
+    constexpr int NPATCH = CIN * 10 * 34, NPE = (NPATCH + 255) / 256;
+    __shared__ float patch[CIN * 10 * PW];
+    __shared__ __attribute__((aligned(16))) uint4 a_img[3 * KS * 2 * 256];
+    __shared__ float out_s[32 * 65];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.x, b = blockIdx.z;
+    const int y0 = blockIdx.y * 8;
+
+    // B operand: this lane's 8 k of output channel cb*32 + i, per k-step and split
+    bf16x8 bw[KS][3];
+    {
+        const int co = cb * 32 + i;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            unsigned pk[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k0 = 16 * s + 8 * h + 2 * j;
+                const float v0 = (k0 < KT && co < Cout) ? w[(size_t)co * KT + k0] : 0.f;
+                const float v1 = (k0 + 1 < KT && co < Cout) ? w[(size_t)co * KT + k0 + 1] : 0.f;
+                split3_pair(v0, v1, pk[0][j], pk[1][j], pk[2][j]);
+            }
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const uint4 t = make_uint4(pk[sp][0], pk[sp][1], pk[sp][2], pk[sp][3]);
+                bw[s][sp] = *reinterpret_cast<const bf16x8*>(&t);
+            }
+        }
+    }
+    const float bv = (cb * 32 + i < Cout) ? bias[cb * 32 + i] : 0.f;
+
+    // builder: thread P = tid builds position P = tile (tid >> 5) x row index (tid & 31) of the MFMA layout
+    const int bt = tid >> 5, bi = tid & 31;
+    const int prow = ((bt >> 1) >> 1) * 4 + (bt & 1) * 2 + ((bi >> 1) & 1);
+    const int pcol = ((bt >> 1) & 1) * 16 + 2 * (bi >> 2) + (bi & 1);
+
+    const float* xb = x + (size_t)b * CIN * H * W;
+    float pin[NPE];
+    auto fetch = [&](int tx) {
+        const int x0 = tx * 32;
+#pragma unroll
+        for (int e = 0; e < NPE; ++e) {
+            const int idx = tid + e * 256;
+            const int c = idx / 340, rem = idx - c * 340;
+            const int r = rem / 34, col = rem - r * 34;
+            const int iy = y0 - 1 + r, ix = x0 - 1 + col;
+            pin[e] = (idx < NPATCH && iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((size_t)c * H + iy) * W + ix] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int tx = 0; tx < tiles_x; ++tx) {
+#pragma unroll
+        for (int e = 0; e < NPE; ++e) {
+            const int idx = tid + e * 256;
+            const int c = idx / 340, rem = idx - c * 340;
+            const int r = rem / 34, col = rem - r * 34;
+            if (idx < NPATCH) patch[(c * 10 + r) * PW + col] = pin[e];
+        }
+        __syncthreads();                                    // patch complete; out_s of the last tile consumed
+        if (tx + 1 < tiles_x) fetch(tx + 1);
+        {
+            float v[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                if (k < KT) {
+                    const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+                    v[k] = patch[(c * 10 + prow + ky) * PW + pcol + kx];
+                } else {
+                    v[k] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    unsigned pk[3][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        split3_pair(v[16 * s + 8 * hh + 2 * j], v[16 * s + 8 * hh + 2 * j + 1], pk[0][j], pk[1][j], pk[2][j]);
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp)
+                        a_img[((sp * KS + s) * 2 + hh) * 256 + tid] = make_uint4(pk[sp][0], pk[sp][1], pk[sp][2], pk[sp][3]);
+                }
+        }
+        __syncthreads();                                    // A image complete
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    const uint4 t = a_img[((sp * KS + s) * 2 + h) * 256 + (wave * 2 + m) * 32 + i];
+                    a[sp] = *reinterpret_cast<const bf16x8*>(&t);
+                }
+                constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TI[t]], bw[s][TJ[t]], acc[m], 0, 0, 0);
+            }
+        }
+        // registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h (conv.hip layout); channel = lane & 31
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = fmaxf(fmaxf(acc[m][4 * q], acc[m][4 * q + 1]), fmaxf(acc[m][4 * q + 2], acc[m][4 * q + 3])) + bv;
+                out_s[i * 65 + (wy * 2 + m) * 16 + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
+            }
+        __syncthreads();                                    // pooled tile complete (and every wave is past its A reads)
+        const int py0 = y0 >> 1, px0 = tx * 16;
+        if ((Wp & 3) == 0 && py0 + 4 <= Hp && px0 + 16 <= Wp && (cb + 1) * 32 <= Cout) {
+            for (int idx = tid; idx < 32 * 16; idx += 256) {
+                const int x4 = idx & 3, py = (idx >> 2) & 3, c = idx >> 4;
+                const float* sp = &out_s[c * 65 + py * 16 + 4 * x4];
+                *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * 32 + c) * Hp + py0 + py) * Wp + px0 + 4 * x4) =
+                    make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+        } else {
+            for (int idx = tid; idx < 32 * 64; idx += 256) {
+                const int px = idx & 15, py = (idx >> 4) & 3, c = idx >> 6;
+                if (cb * 32 + c < Cout && py0 + py < Hp && px0 + px < Wp)
+                    y[(((size_t)b * Cout + cb * 32 + c) * Hp + py0 + py) * Wp + px0 + px] = out_s[c * 65 + py * 16 + px];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool i2l_conv_bf16x3_applicable(int Cin, int Cout) {
@@ -327,6 +476,24 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     else if (wx == 1) I2L_LAUNCH3(1);
     else I2L_LAUNCH3(4);
 #undef I2L_LAUNCH3
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+bool i2l_conv_smallk_applicable(int Cin, int Cout) {
+    static const bool exact = getenv("I2L_CONV_EXACT_FP32") != nullptr && atoi(getenv("I2L_CONV_EXACT_FP32")) != 0;
+    return !exact && Cin >= 1 && Cin <= 3 && Cout % 32 == 0;
+}
+
+int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                        hipStream_t s) {
+    const int Hp = H / 2, Wp = W / 2;
+    const int tiles_x = i2l_cdiv(2 * Wp, 32), bands = i2l_cdiv(2 * Hp, 8);
+    if (bands > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
+    dim3 grid(Cout / 32, bands, B);
+    if (Cin == 1) hipLaunchKernelGGL(conv3x3_smallk_bf16x3_kernel<1>, grid, dim3(256), 0, s, x, w, bias, y, H, W, Cout, Hp, Wp, tiles_x);
+    else if (Cin == 2) hipLaunchKernelGGL(conv3x3_smallk_bf16x3_kernel<2>, grid, dim3(256), 0, s, x, w, bias, y, H, W, Cout, Hp, Wp, tiles_x);
+    else hipLaunchKernelGGL(conv3x3_smallk_bf16x3_kernel<3>, grid, dim3(256), 0, s, x, w, bias, y, H, W, Cout, Hp, Wp, tiles_x);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }

@@ -190,7 +190,9 @@ def test_conv_kernel_odd_shapes():
                                  (1, 32, 32, 160, 64), (2, 1, 2, 2, 64),
                                  # split-bf16 matrix-core kernel: every tile shape, ragged edges, 3 chunks
                                  (2, 16, 9, 13, 64), (2, 32, 25, 100, 64), (3, 64, 12, 50, 128), (1, 48, 37, 19, 192),
-                                 (2, 16, 2, 2, 64)]:
+                                 (2, 16, 2, 2, 64),
+                                 # first-block kernel (K = 9 Cin <= 27 in one or two bf16 k-steps)
+                                 (2, 1, 50, 200, 32), (1, 2, 9, 13, 64), (3, 3, 17, 33, 32), (1, 3, 8, 64, 96)]:
         x, w, b = torch.randn(B, Cin, H, W), torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5), torch.randn(Cout)
         want = O.conv_block(x, w, b)
         y = torch.empty(B, Cout, H // 2, W // 2, device=DEV)
