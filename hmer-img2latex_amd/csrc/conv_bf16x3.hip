@@ -287,22 +287,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// First conv block (Cin <= 3: K = 9 Cin <= 27): the whole K fits ONE or TWO bf16 MFMA k-steps, so the filter bank
-// (32 output channels x 32 k x 3 splits) lives in 24 registers per lane for the whole kernel and the A operand is an
-// im2col image built in LDS: thread P gathers the <= 27 taps of conv position P from a staged fp32 patch, splits
-// them and writes [split][k-step][k half][position][8 k] -- 16-byte pieces in position order, so a wave's
-// ds_read_b128 of one (split, k-step) is 1 KiB contiguous.  A workgroup walks the column tiles of an 8-row band
-// (8 x 32 positions per tile, 2 M-tiles per wave, 12 MFMAs per M-tile) with the next patch prefetched in registers.
+// First conv block (Cin <= 3).  The staged input patch is kept channels-last and already split: one 8-byte pixel
+// {c0, c1, c2, 0} per split, so a lane's A operand of one k-step is just TWO pixels (two taps x 4 channels = 8 k)
+// read by two ds_read_b64 -- no im2col image, no per-tap splitting.  K = 9 taps x 4 = 36 -> 3 k-steps of 16 (taps
+// 9..11 carry zero weights); the filter bank (32 output channels x 48 k x 3 splits) sits in 36 registers per lane
+// for the whole kernel.  A workgroup walks the column tiles of an 8-row band (8 x 32 positions per tile, 2 M-tiles
+// per wave, 18 MFMAs per M-tile) with the next patch prefetched in registers; ~20 KB of LDS and <= 128 registers
+// let four workgroups share a CU, so one's staging / epilogue hides behind the others' MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
 template <int CIN>
-__global__ __launch_bounds__(256, 2) void conv3x3_smallk_bf16x3_kernel(
+__global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     int H, int W, int Cout, int Hp, int Wp, int tiles_x) {
-    constexpr int KT = CIN * 9, KS = (KT + 15) / 16, KP = KS * 16;
-    constexpr int PW = 48;                                   // patch row stride: rows r, r+1 on disjoint halves of the 32 banks
-    constexpr int NPATCH = CIN * 10 * 34, NPE = (NPATCH + 255) / 256;
-    __shared__ float patch[CIN * 10 * PW];
-    __shared__ __attribute__((aligned(16))) uint4 a_img[3 * KS * 2 * 256];
+    constexpr int RS = 48;                                   // pixels per patch row: rows r, r+1 half a bank row apart
+    constexpr int PLANE = 10 * RS;                           // pixels per split plane
+    __shared__ __attribute__((aligned(16))) uint2 img[3 * PLANE];
     __shared__ float out_s[32 * 65];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,18 +310,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_smallk_bf16x3_kernel(
     const int cb = blockIdx.x, b = blockIdx.z;
     const int y0 = blockIdx.y * 8;
 
-    // B operand: this lane's 8 k of output channel cb*32 + i, per k-step and split
-    bf16x8 bw[KS][3];
+    // B operand: k-step s, lane half h -> taps 4s + 2h, 4s + 2h + 1, channels 0..3 each
+    bf16x8 bw[3][3];
     {
         const int co = cb * 32 + i;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s = 0; s < 3; ++s) {
             unsigned pk[3][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k0 = 16 * s + 8 * h + 2 * j;
-                const float v0 = (k0 < KT && co < Cout) ? w[(size_t)co * KT + k0] : 0.f;
-                const float v1 = (k0 + 1 < KT && co < Cout) ? w[(size_t)co * KT + k0 + 1] : 0.f;
+                const int tap = 4 * s + 2 * h + (j >> 1), c0 = 2 * (j & 1);
+                const bool okt = tap < 9 && co < Cout;
+                const float v0 = (okt && c0 < CIN) ? w[((size_t)co * CIN + c0) * 9 + tap] : 0.f;
+                const float v1 = (okt && c0 + 1 < CIN) ? w[((size_t)co * CIN + c0 + 1) * 9 + tap] : 0.f;
                 split3_pair(v0, v1, pk[0][j], pk[1][j], pk[2][j]);
             }
 #pragma unroll
@@ -334,71 +334,71 @@ __global__ __launch_bounds__(256, 2) void conv3x3_smallk_bf16x3_kernel(
     }
     const float bv = (cb * 32 + i < Cout) ? bias[cb * 32 + i] : 0.f;
 
-    // builder: thread P = tid builds position P = tile (tid >> 5) x row index (tid & 31) of the MFMA layout
-    const int bt = tid >> 5, bi = tid & 31;
-    const int prow = ((bt >> 1) >> 1) * 4 + (bt & 1) * 2 + ((bi >> 1) & 1);
-    const int pcol = ((bt >> 1) & 1) * 16 + 2 * (bi >> 2) + (bi & 1);
+    // A operand addresses (pixel units): M-tile m covers rows wy*4 + 2m + dy, cols wx*16 + 2pp + dx
+    const int pbase = (wy * 4 + ((i >> 1) & 1)) * RS + wx * 16 + 2 * (i >> 2) + (i & 1);
+    int aoff[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int tap = min(4 * s + 2 * h + e, 8);       // taps >= 9 have zero weights: read any valid pixel
+            aoff[s][e] = pbase + (tap / 3) * RS + (tap % 3);
+        }
 
+    // staging: pixel q = tid, tid + 256 of the 10 x 34 patch
     const float* xb = x + (size_t)b * CIN * H * W;
-    float pin[NPE];
+    const size_t HW = (size_t)H * W;
+    int q_lds[2], q_col[2];
+    long q_goff[2];
+    bool q_rowok[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int q = tid + e * 256;
+        const int r = q / 34, col = q - r * 34;
+        const int iy = y0 - 1 + r;
+        q_lds[e] = q < 340 ? r * RS + col : -1;
+        q_col[e] = col - 1;
+        q_rowok[e] = q < 340 && iy >= 0 && iy < H;
+        q_goff[e] = (long)iy * W + col - 1;
+    }
+    float pin[2][CIN];
     auto fetch = [&](int tx) {
         const int x0 = tx * 32;
 #pragma unroll
-        for (int e = 0; e < NPE; ++e) {
-            const int idx = tid + e * 256;
-            const int c = idx / 340, rem = idx - c * 340;
-            const int r = rem / 34, col = rem - r * 34;
-            const int iy = y0 - 1 + r, ix = x0 - 1 + col;
-            pin[e] = (idx < NPATCH && iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((size_t)c * H + iy) * W + ix] : 0.f;
+        for (int e = 0; e < 2; ++e) {
+            const int ix = x0 + q_col[e];
+            const bool ok = q_rowok[e] && ix >= 0 && ix < W;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) pin[e][c] = ok ? xb[c * HW + q_goff[e] + x0] : 0.f;
         }
     };
     fetch(0);
     for (int tx = 0; tx < tiles_x; ++tx) {
 #pragma unroll
-        for (int e = 0; e < NPE; ++e) {
-            const int idx = tid + e * 256;
-            const int c = idx / 340, rem = idx - c * 340;
-            const int r = rem / 34, col = rem - r * 34;
-            if (idx < NPATCH) patch[(c * 10 + r) * PW + col] = pin[e];
+        for (int e = 0; e < 2; ++e) {
+            if (q_lds[e] >= 0) {
+                unsigned p0[3], p1[3];
+                split3_pair(pin[e][0], CIN > 1 ? pin[e][CIN > 1 ? 1 : 0] : 0.f, p0[0], p0[1], p0[2]);
+                split3_pair(CIN > 2 ? pin[e][CIN > 2 ? 2 : 0] : 0.f, 0.f, p1[0], p1[1], p1[2]);
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) img[sp * PLANE + q_lds[e]] = make_uint2(p0[sp], p1[sp]);
+            }
         }
         __syncthreads();                                    // patch complete; out_s of the last tile consumed
         if (tx + 1 < tiles_x) fetch(tx + 1);
-        {
-            float v[KP];
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                if (k < KT) {
-                    const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
-                    v[k] = patch[(c * 10 + prow + ky) * PW + pcol + kx];
-                } else {
-                    v[k] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    unsigned pk[3][4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        split3_pair(v[16 * s + 8 * hh + 2 * j], v[16 * s + 8 * hh + 2 * j + 1], pk[0][j], pk[1][j], pk[2][j]);
-#pragma unroll
-                    for (int sp = 0; sp < 3; ++sp)
-                        a_img[((sp * KS + s) * 2 + hh) * 256 + tid] = make_uint4(pk[sp][0], pk[sp][1], pk[sp][2], pk[sp][3]);
-                }
-        }
-        __syncthreads();                                    // A image complete
         f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < 3; ++s) {
                 bf16x8 a[3];
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp) {
-                    const uint4 t = a_img[((sp * KS + s) * 2 + h) * 256 + (wave * 2 + m) * 32 + i];
+                    const uint2 t0 = img[sp * PLANE + m * 2 * RS + aoff[s][0]];
+                    const uint2 t1 = img[sp * PLANE + m * 2 * RS + aoff[s][1]];
+                    const uint4 t = make_uint4(t0.x, t0.y, t1.x, t1.y);
                     a[sp] = *reinterpret_cast<const bf16x8*>(&t);
                 }
                 constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
