@@ -14,6 +14,8 @@
 // operand read (32 lanes walk 32 rows at one k) is bank-conflict-free.
 // Split-K / batch: grid.z slices write fp32 partial slabs; a second kernel sums the slabs in
 // slice order (deterministic) and applies bias/ReLU/permutation/alpha/accumulate.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -22,6 +24,15 @@ constexpr int BM = 64, BN = 64, BK = 64, LDP = BK + 1;
 constexpr int NLD = BM * BK / 4 / 256;      // float4 loads per thread per operand tile
 constexpr int KQ = BK / 4;                  // float4 chunks along k
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Split-K slabs are written by concurrent workgroups and summed slab by slab at the same (m, n): a power-of-two slab
+// stride (256 x 256 floats = 256 KB) puts all of those accesses on one memory channel (measured: 16.7 MB of slab
+// writes took 42 us).  The stride is therefore an ODD number of 256-byte units.
+__host__ __device__ __forceinline__ size_t slab_stride(int M, int N) {
+    size_t units = ((size_t)M * N + 63) / 64;               // 256-byte units
+    if ((units & 1) == 0) ++units;
+    return units * 64;
+}
 
 __device__ __forceinline__ int perm_col(int n, int perm_h) {
     if (perm_h <= 0) return n;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, float* __restrict
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (m < g.M && n < g.N) {
-            if (slabs > 1) partial[((size_t)slab * g.M + m) * g.N + n] = acc[r];
+            if (slabs > 1) partial[(size_t)slab * slab_stride(g.M, g.N) + (size_t)m * g.N + n] = acc[r];
             else epilogue_store(g, m, n, acc[r]);
         }
     }
@@ -150,11 +161,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, float* __restrict
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const float* __restrict__ partial,
                                                             int slabs) {
-    const size_t total = (size_t)g.M * g.N;
+    const size_t total = (size_t)g.M * g.N, stride = slab_stride(g.M, g.N);
     for (size_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int m = (int)(i / g.N), n = (int)(i - (size_t)m * g.N);
         float v = 0.f;
-        for (int s = 0; s < slabs; ++s) v += partial[(size_t)s * total + i];   // fixed slab order
+        int s = 0;
+        for (; s + 8 <= slabs; s += 8) {                    // 8 loads in flight, added in slab order
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = partial[(size_t)(s + j) * stride + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += t[j];
+        }
+        for (; s < slabs; ++s) v += partial[(size_t)s * stride + i];
         epilogue_store(g, m, n, v);
     }
 }
@@ -180,13 +199,168 @@ void launch(const GemmArgs& g, float* ws, int kc, int ks, int slabs, bool vec, d
     else hipLaunchKernelGGL((gemm_kernel<A_KC, W_KC, false>), grid, dim3(256), 0, s, g, ws, kc, ks, slabs);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// y = act(x W^T + b) with a long reduction (the encoder's Flatten -> Linear: K = 40,960) on the bf16 matrix cores at
+// fp32-grade accuracy: both operands are split into 3 bf16 pieces on their way to LDS (x = x0 + x1 + x2, exact) and
+// a product is the six partial products a_i b_j, i + j <= 2, on v_mfma_f32_32x32x16_bf16 -- see conv_bf16x3.hip.
+// Tile 128 x 64 x 32 per 256-thread workgroup (waves 2 x 2, each 64 x 32 = 2 M-tiles), split-K into fp32 slabs that
+// splitk_reduce_kernel sums in slab order.  LDS image per operand: [split][k group of 8][row][8 k] in 16-byte pieces,
+// plane stride = rows + 2 pieces, so both the staging writes (4 lanes = the 4 k groups of one row) and the MFMA
+// operand reads (32 lanes = 32 consecutive rows) are conflict-free.  Workgroups that share a K slice (same operand
+// bytes) get block ids that are equal mod 8: one XCD, one L2 (speed only).
+// ---------------------------------------------------------------------------------------------------------------
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
+typedef float f32v2_t __attribute__((ext_vector_type(2)));
+constexpr int LBM = 128, LBN = 64, LBK = 32, LPA = LBM + 2, LPW = LBN + 2;
+
+__device__ __forceinline__ void lsplit3_pair(float x0, float x1, unsigned& s0, unsigned& s1, unsigned& s2) {
+    f32v2_t v = {x0, x1};
+    bf16v2_t b0 = __builtin_convertvector(v, bf16v2_t);
+    v -= __builtin_convertvector(b0, f32v2_t);
+    bf16v2_t b1 = __builtin_convertvector(v, bf16v2_t);
+    v -= __builtin_convertvector(b1, f32v2_t);
+    bf16v2_t b2 = __builtin_convertvector(v, bf16v2_t);
+    s0 = *reinterpret_cast<unsigned*>(&b0);
+    s1 = *reinterpret_cast<unsigned*>(&b1);
+    s2 = *reinterpret_cast<unsigned*>(&b2);
+}
+// 8 consecutive k of one row -> one 16-byte piece per split
+__device__ __forceinline__ void lsplit_piece(const float4& lo, const float4& hi, uint4 (&out)[3]) {
+    unsigned p[3][4];
+    lsplit3_pair(lo.x, lo.y, p[0][0], p[1][0], p[2][0]);
+    lsplit3_pair(lo.z, lo.w, p[0][1], p[1][1], p[2][1]);
+    lsplit3_pair(hi.x, hi.y, p[0][2], p[1][2], p[2][2]);
+    lsplit3_pair(hi.z, hi.w, p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) out[sp] = make_uint4(p[sp][0], p[sp][1], p[sp][2], p[sp][3]);
+}
+
+__global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(GemmArgs g, float* __restrict__ partial, int k_chunk,
+                                                               int S, int tiles_n, int tiles) {
+    __shared__ __attribute__((aligned(16))) uint4 a_s[3 * 4 * LPA];
+    __shared__ __attribute__((aligned(16))) uint4 w_s[3 * 4 * LPW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int L = blockIdx.x, grp = L >> 3;
+    const int tile = grp % tiles, slice = (L & 7) + 8 * (grp / tiles);
+    if (slice >= S) return;
+    const int m0 = (tile / tiles_n) * LBM, n0 = (tile % tiles_n) * LBN;
+    const int kbeg = slice * k_chunk, kend = min(g.K, kbeg + k_chunk);
+
+    // staging: piece = (row, k group kg of 8); A: 2 pieces per thread, W: 1
+    const int srow = tid >> 2, skg = tid & 3;
+    const float* pa0 = g.A + (size_t)min(m0 + srow, g.M - 1) * g.lda + skg * 8;
+    const float* pa1 = g.A + (size_t)min(m0 + 64 + srow, g.M - 1) * g.lda + skg * 8;
+    const float* pw = g.W + (size_t)min(n0 + srow, g.N - 1) * g.ldw + skg * 8;
+    const bool oka0 = m0 + srow < g.M, oka1 = m0 + 64 + srow < g.M, okw = n0 + srow < g.N;
+    // three register stages: the loads of chunk c+2 are issued while chunk c computes (one chunk of MFMAs is only
+    // ~0.4 us, shorter than a memory round trip)
+    struct Stage { float4 a[2][2], w[2]; };
+    Stage st0, st1, st2;
+    auto fetch = [&](Stage& st, int k0) {
+        const bool okk = k0 + skg * 8 < kend;               // K % 8 == 0: a piece is inside or outside as a whole
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.a[0][0] = (oka0 && okk) ? *reinterpret_cast<const float4*>(pa0 + k0) : z;
+        st.a[0][1] = (oka0 && okk) ? *reinterpret_cast<const float4*>(pa0 + k0 + 4) : z;
+        st.a[1][0] = (oka1 && okk) ? *reinterpret_cast<const float4*>(pa1 + k0) : z;
+        st.a[1][1] = (oka1 && okk) ? *reinterpret_cast<const float4*>(pa1 + k0 + 4) : z;
+        st.w[0] = (okw && okk) ? *reinterpret_cast<const float4*>(pw + k0) : z;
+        st.w[1] = (okw && okk) ? *reinterpret_cast<const float4*>(pw + k0 + 4) : z;
+    };
+    auto commit = [&](const Stage& st) {
+        uint4 o[3];
+        lsplit_piece(st.a[0][0], st.a[0][1], o);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + skg) * LPA + srow] = o[sp];
+        lsplit_piece(st.a[1][0], st.a[1][1], o);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + skg) * LPA + 64 + srow] = o[sp];
+        lsplit_piece(st.w[0], st.w[1], o);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) w_s[(sp * 4 + skg) * LPW + srow] = o[sp];
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    auto step = [&](const Stage& cur, Stage& nxt2, int k0) {
+        commit(cur);
+        __syncthreads();
+        if (k0 + 2 * LBK < kend) fetch(nxt2, k0 + 2 * LBK);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t a[2][3], b[3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const int plane = sp * 4 + s * 2 + h;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const uint4 t = a_s[plane * LPA + wm * 64 + m * 32 + i];
+                    a[m][sp] = *reinterpret_cast<const bf16x8_t*>(&t);
+                }
+                const uint4 t = w_s[plane * LPW + wn * 32 + i];
+                b[sp] = *reinterpret_cast<const bf16x8_t*>(&t);
+            }
+            constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][TI[t]], b[TJ[t]], acc[m], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+    fetch(st0, kbeg);
+    if (kbeg + LBK < kend) fetch(st1, kbeg + LBK);
+    for (int k0 = kbeg; k0 < kend; k0 += 3 * LBK) {
+        step(st0, st2, k0);
+        if (k0 + LBK < kend) step(st1, st0, k0 + LBK);
+        if (k0 + 2 * LBK < kend) step(st2, st1, k0 + 2 * LBK);
+    }
+    const int n = n0 + wn * 32 + i;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < g.M && n < g.N) {
+                if (S > 1) partial[(size_t)slice * slab_stride(g.M, g.N) + (size_t)row * g.N + n] = acc[m][r];
+                else epilogue_store(g, row, n, acc[m][r]);
+            }
+        }
+}
+
+void plan_bf16x3(int M, int N, int K, int* S, int* k_chunk) {
+    const int tiles = i2l_cdiv(M, LBM) * i2l_cdiv(N, LBN);
+    int s = 512 / tiles;
+    const int max_s = K / 256;                // keep >= 256 of K per slice
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    int kc = i2l_cdiv(i2l_cdiv(K, s), LBK) * LBK;
+    *S = i2l_cdiv(K, kc);
+    *k_chunk = kc;
+}
+
+bool linear_bf16x3_applicable(const float* x, const float* w, int M, int K, int N) {
+    static const bool exact = getenv("I2L_CONV_EXACT_FP32") != nullptr && atoi(getenv("I2L_CONV_EXACT_FP32")) != 0;
+    (void)M; (void)N;
+    return !exact && K >= 2048 && K % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+           reinterpret_cast<uintptr_t>(w) % 16 == 0;
+}
+
 }  // namespace
 
 size_t i2l_gemm_workspace_bytes(int M, int N, int K, int nz) {
     int ks, kc;
     plan(M, N, K, nz < 1 ? 1 : nz, &ks, &kc);
     const size_t slabs = (size_t)ks * (nz < 1 ? 1 : nz);
-    return slabs > 1 ? i2l_align(slabs * M * N * sizeof(float)) : 0;
+    return slabs > 1 ? i2l_align(slabs * slab_stride(M, N) * sizeof(float)) : 0;
 }
 
 int i2l_gemm(const GemmArgs& g0, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -197,7 +371,7 @@ int i2l_gemm(const GemmArgs& g0, void* ws, size_t ws_bytes, hipStream_t stream) 
     plan(g.M, g.N, g.K, g.nz, &ks, &kc);
     const int slabs = ks * g.nz;
     if (slabs > 65535) return I2L_ERR_UNSUPPORTED;
-    if (slabs > 1 && (!ws || ws_bytes < (size_t)slabs * g.M * g.N * sizeof(float))) return I2L_ERR_WORKSPACE;
+    if (slabs > 1 && (!ws || ws_bytes < (size_t)slabs * slab_stride(g.M, g.N) * sizeof(float))) return I2L_ERR_WORKSPACE;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     const bool vec = al16(g.A) && al16(g.W) && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.bsa % 4 == 0 && g.bsw % 4 == 0 &&
                      (g.a_kc && g.w_kc ? g.K % 4 == 0 : true);
@@ -220,7 +394,14 @@ int i2l_gemm(const GemmArgs& g0, void* ws, size_t ws_bytes, hipStream_t stream) 
 
 extern "C" size_t i2l_linear_workspace_bytes(int M, int K, int N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    return i2l_gemm_workspace_bytes(M, N, K, 1);
+    size_t need = i2l_gemm_workspace_bytes(M, N, K, 1);
+    if (K >= 2048 && K % 8 == 0) {            // the split-bf16 path's slabs (linear_bf16x3_kernel)
+        int S, kc;
+        plan_bf16x3(M, N, K, &S, &kc);
+        const size_t n3 = S > 1 ? i2l_align((size_t)S * slab_stride(M, N) * sizeof(float)) : 0;
+        if (n3 > need) need = n3;
+    }
+    return need;
 }
 
 extern "C" int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -234,6 +415,24 @@ extern "C" int i2l_linear_bias_act_fwd(const float* x, const float* w, const flo
     g.C = y; g.ldc = N;
     g.M = M; g.N = N; g.K = K;
     g.relu = relu ? 1 : 0;
+    if (linear_bf16x3_applicable(x, w, M, K, N)) {
+        int S, kc;
+        plan_bf16x3(M, N, K, &S, &kc);
+        if (S > 1 && (!workspace || workspace_bytes < (size_t)S * slab_stride(M, N) * sizeof(float))) return I2L_ERR_WORKSPACE;
+        const int tiles_n = i2l_cdiv(N, LBN), tiles = i2l_cdiv(M, LBM) * tiles_n;
+        hipStream_t s = i2l_s(stream);
+        hipLaunchKernelGGL(linear_bf16x3_kernel, dim3(8 * tiles * i2l_cdiv(S, 8)), dim3(256), 0, s, g,
+                           static_cast<float*>(workspace), kc, S, tiles_n, tiles);
+        I2L_CHECK_LAUNCH();
+        if (S > 1) {
+            const size_t total = (size_t)M * N;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, (const float*)workspace, S);
+            I2L_CHECK_LAUNCH();
+        }
+        return I2L_OK;
+    }
     return i2l_gemm(g, workspace, workspace_bytes, i2l_s(stream));
 }
 

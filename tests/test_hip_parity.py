@@ -168,7 +168,9 @@ def test_cfg2_batch256_ids(fname):
 def test_linear_kernel_odd_shapes():
     torch.manual_seed(0)
     L = _lib.lib()
-    for (M, K, N, relu) in [(1, 7, 3, 0), (5, 33, 70, 1), (67, 130, 65, 1), (4, 4096, 33, 0), (256, 1024, 96, 1)]:
+    for (M, K, N, relu) in [(1, 7, 3, 0), (5, 33, 70, 1), (67, 130, 65, 1), (4, 4096, 33, 0), (256, 1024, 96, 1),
+                            # long reductions: the split-bf16 matrix-core kernel (ragged tiles, K tail, full FC size)
+                            (130, 2056, 70, 1), (256, 40960, 256, 1), (3, 8192, 200, 0)]:
         x, w, b = torch.randn(M, K), torch.randn(N, K) / K ** 0.5, torch.randn(N)
         want = torch.nn.functional.linear(x, w, b)
         want = want.relu() if relu else want
