@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 900 -- 'bash profiles/collect.sh r01 v3'
+# Writes gpurun_out/prof_<tag>/{stats,fetch,write}/ ; profiles/summarize.py turns them into the committed files.
+# Counters are collected in their own passes (never together with a trace domain other than kernel-trace).
+set -e
+ROUND=${1:-r01}; TAG=${2:-v3}
+OUT=gpurun_out/prof_${ROUND}_${TAG}
+export TMPDIR=/tmp
+mkdir -p $OUT
+python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python bench.py --steps 20 --warmup 3 > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python bench.py --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- python bench.py --steps 3 --warmup 1 > $OUT/write.log 2>&1
+find $OUT -name "*.csv" | head -20
