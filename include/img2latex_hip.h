@@ -48,7 +48,12 @@ const char* i2l_error_string(int code);
 
 /* One CNN block: y = maxpool2x2(relu(conv3x3_pad1(x, w) + bias)), floor pooling.
  * Replaces nn.Conv2d + nn.ReLU + nn.MaxPool2d, encoder.py:78-95 executed at :122.
- * x (B,Cin,H,W)  w (Cout,Cin,3,3)  bias (Cout)  y (B,Cout,H/2,W/2), NCHW fp32. */
+ * x (B,Cin,H,W)  w (Cout,Cin,3,3)  bias (Cout)  y (B,Cout,H/2,W/2), NCHW fp32.
+ * Arithmetic: with argmax_out == NULL (inference) and Cin <= 3 or Cin % 16 == 0, Cout % 32/64 == 0 the products
+ * run on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces (six partial
+ * products, fp32 accumulation): fp32-grade results (~2^-24 relative per product), not bit-identical to an fmaf
+ * chain.  Environment I2L_CONV_EXACT_FP32=1, a non-NULL argmax_out (training) and other shapes use the exact
+ * fp32 kernels.  The same applies to i2l_linear_bias_act_fwd for K >= 2048. */
 size_t i2l_conv_workspace_bytes(int Cin, int Cout);   /* packed-weight scratch; 0 when none is needed */
 /* argmax_out: NULL, or (B,Cout,H/2,W/2) uint8 receiving the position 2*dy+dx of each pooling
  * window's maximum (first maximum wins, as ATen) -- what the backward pass needs. */
@@ -150,7 +155,8 @@ int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* enc, int rows
  * output projection, token selection], one persistent launch, no host sync inside.
  * Replaces the loops at seq2seq.py:210-221 and predictor.py:283-347 and, with
  * steps == 1, LSTMDecoder.decode_step (decoder.py:197-284).
- *   workspace   filled by i2l_decoder_prepare() for these `rows`
+ *   workspace   filled by i2l_decoder_prepare() for these `rows`; its trailing scratch region (exchange
+ *               granules of the grouped kernel) is WRITTEN by the call: one decode at a time per workspace
  *   tok0        (rows) int32 first input token of every row
  *   forced      (rows, steps) int32 or NULL; if given, the input token of step t is
  *               forced[r][t] (teacher forcing) instead of the previous selection
@@ -158,7 +164,12 @@ int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* enc, int rows
  *   ids_out     (rows, steps) int32 or NULL   selected token per step
  *   logits_out  (rows, steps, V) or NULL      raw logits (before temperature)
  *   h_out,c_out (L, rows, H) or NULL          state after the last executed step
- * First index wins ties, as torch.argmax. */
+ * First index wins ties, as torch.argmax.
+ * Kernel choice: L == 1, H == 256, V <= 512, select == I2L_SELECT_LOGITS, no state in/out, steps >= 8 run the
+ * grouped kernel (4 workgroups share 4 rows and keep the weights on chip, in-launch exchanges bounded by a 3 s
+ * wall-clock limit); everything else the row-per-workgroup kernel.  If a bounded wait expires (GPU heavily
+ * oversubscribed) every id of the affected rows is -3 and no other output is defined; I2L_DECODE_GROUP=0 in the
+ * environment disables the grouped kernel. */
 int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
                       const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
                       float temperature, int select, int stop, int end_id,
@@ -166,7 +177,7 @@ int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int r
                       i2l_stream_t stream);
 
 /* Same as i2l_greedy_decode with an explicit number of batch rows per workgroup (0 = automatic, else 1, 2
- * or 4).  Rows per workgroup > 1 leaves compute units free for another stream (the weight stream of a
+ * or 4; a non-zero value also selects the row-per-workgroup kernel).  Rows per workgroup > 1 leaves compute units free for another stream (the weight stream of a
  * workgroup is shared by its rows): GreedyPipeline runs the decode of batch i on half of the chip while the
  * encoder of batch i+1 runs on the other half.  Results do not depend on this parameter. */
 int i2l_greedy_decode_ex(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
