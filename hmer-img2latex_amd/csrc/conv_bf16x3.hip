@@ -95,60 +95,59 @@ template <int WX>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wpack, const float* __restrict__ bias,
     float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
-    int tiles_x, int n_chunks) {
+    int tiles_x, int n_chunks, int tiles_per_img, int n_items, int items_per_wg) {
     typedef Tile3<WX> TL;
     constexpr int PR = TL::TR / 2, PC = TL::TC / 2;
-    constexpr int OUT_F = CO_BLK * 65;                              // fp32 staging of the pooled tile
-    constexpr int IN_BYTES = TL::IN_U4 * 16 > OUT_F * 4 ? TL::IN_U4 * 16 : OUT_F * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char in_raw[IN_BYTES];
+    __shared__ __attribute__((aligned(16))) uint4 in_s[TL::IN_U4];
     __shared__ __attribute__((aligned(16))) uint4 w_s[W_PHASE_U4];             // the 3 taps of one filter row
+    __shared__ float out_s[CO_BLK * 65];                                       // fp32 staging of the pooled tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave / WX, wx = wave % WX;
     const int cb = blockIdx.x;
-    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
-    const int b = blockIdx.z;
-    const int y0 = ty * TL::TR, x0 = tx * TL::TC;
     const int i = lane & 31, h = lane >> 5;
     const int dx = i & 1, dy = (i >> 1) & 1, pp = i >> 2;
     // operand bases in 16-byte pieces
     const int a_base = ((wy * 4 + dy) * 2 + h) * TL::ICP + wx * 16 + 2 * pp + dx;
     const int b_base = h * CO_BLK + i;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    const float* xb = x + (size_t)b * Cin * H * W;
     const uint4* wp_cb = reinterpret_cast<const uint4*>(wpack) + (size_t)cb * n_chunks * W_SLAB_U4;
+    const int HW = H * W;
 
     // staging plan: piece e of this thread = 8 consecutive channels (half lh) of patch position (r, col)
     constexpr int NP = TL::IR * 2 * TL::IC;
     constexpr int NE = (NP + 255) / 256;
     constexpr int NWV = (W_PHASE_U4 + 255) / 256;
     constexpr int SPLIT_U4 = TL::IR * TL::ROW16;                    // 16-byte pieces between split planes
-    int loff[NE], goff[NE];
-    unsigned okmask = 0;
+    int loff[NE], p_r[NE], p_col[NE], p_lh[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int idx = tid + e * 256;
-        const int col = idx % TL::IC;
-        const int lh = (idx / TL::IC) & 1;
-        const int r = idx / (2 * TL::IC);
-        const int iy = y0 - 1 + r, ix = x0 - 1 + col;
-        loff[e] = idx < NP ? (r * 2 + lh) * TL::ICP + col : -1;
-        goff[e] = (8 * lh * H + iy) * W + ix;
-        if (idx < NP && iy >= 0 && iy < H && ix >= 0 && ix < W) okmask |= 1u << e;
+        p_col[e] = idx % TL::IC;
+        p_lh[e] = (idx / TL::IC) & 1;
+        p_r[e] = idx / (2 * TL::IC);
+        loff[e] = idx < NP ? (p_r[e] * 2 + p_lh[e]) * TL::ICP + p_col[e] : -1;
     }
-    const int HW = H * W;
+    // the item whose chunks are being FETCHED (runs one phase ahead of the item being computed)
+    const float* f_xb = x;
+    int goff[NE];
+    unsigned okmask = 0;
+    auto setup_fetch = [&](int item) {
+        const int fb = item / tiles_per_img, ft = item - fb * tiles_per_img;
+        const int fty = ft / tiles_x, ftx = ft - fty * tiles_x;
+        const int fy0 = fty * TL::TR, fx0 = ftx * TL::TC;
+        f_xb = x + (size_t)fb * Cin * HW;
+        okmask = 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int iy = fy0 - 1 + p_r[e], ix = fx0 - 1 + p_col[e];
+            goff[e] = (8 * p_lh[e] * H + iy) * W + ix;
+            if (loff[e] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W) okmask |= 1u << e;
+        }
+    };
     float xin[NE][8];
     uint4 win[NWV];
     auto fetch_x = [&](int chunk) {
-        const float* xc = xb + (size_t)chunk * CH * HW;
+        const float* xc = f_xb + (size_t)chunk * CH * HW;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const bool ok = (okmask >> e) & 1u;
@@ -164,7 +163,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
             win[e] = idx < W_PHASE_U4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
         }
     };
-    uint4* in_w = reinterpret_cast<uint4*>(in_raw);
     auto commit_x = [&]() {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                 for (int j = 0; j < 4; ++j) split3_pair(xin[e][2 * j], xin[e][2 * j + 1], s[0][j], s[1][j], s[2][j]);
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp)
-                    in_w[loff[e] + sp * SPLIT_U4] = make_uint4(s[sp][0], s[sp][1], s[sp][2], s[sp][3]);
+                    in_s[loff[e] + sp * SPLIT_U4] = make_uint4(s[sp][0], s[sp][1], s[sp][2], s[sp][3]);
             }
         }
     };
@@ -186,99 +184,119 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
         }
     };
 
-    // Two workgroups share a CU (LDS 2 x ~53 KB, <= 256 registers): while one sits in its barriers / staging the
-    // other keeps the matrix cores busy.  Per chunk: 3 phases (filter rows) of 3 taps x 24 MFMAs per wave.
-    const uint4* in_u4 = reinterpret_cast<const uint4*>(in_raw);
+    // Two workgroups share a CU (LDS 2 x ~70 KB, <= 256 registers): while one sits in its barriers / staging the
+    // other keeps the matrix cores busy.  A workgroup walks `items_per_wg` consecutive tiles of its 64-channel block
+    // (the grid is sized to ONE resident round) and the first patch / filter row of the next tile are fetched
+    // during the last phases of the current one, so only the first tile pays a prologue.
+    // Per chunk: 3 phases (filter rows) of 3 taps x 24 MFMAs per wave.
     const int n_phases = 3 * n_chunks;
+    const int it0 = blockIdx.y * items_per_wg, it_end = min(it0 + items_per_wg, n_items);
+    setup_fetch(it0);
     fetch_x(0);
     fetch_w(0);
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    for (int it = it0; it < it_end; ++it) {
+        const int b = it / tiles_per_img, tl = it - b * tiles_per_img;
+        const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+        const int y0 = ty * TL::TR, x0 = tx * TL::TC;
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            __syncthreads();
-            if (ky == 0) commit_x();
-            commit_w();
-            __syncthreads();
-            if (chunk * 3 + ky + 1 < n_phases) fetch_w(chunk * 3 + ky + 1);
-            if (ky == 0 && chunk + 1 < n_chunks) fetch_x(chunk + 1);
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                bf16x8 a[2][3], bw[2][3];
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
 #pragma unroll
-                    for (int sp = 0; sp < 3; ++sp) {
-                        const uint4 t = in_u4[a_base + (sp * TL::IR + m * 2 + ky) * TL::ROW16 + kx];
-                        a[m][sp] = *reinterpret_cast<const bf16x8*>(&t);
-                    }
+            for (int ky = 0; ky < 3; ++ky) {
+                __syncthreads();
+                if (ky == 0) commit_x();
+                commit_w();
+                __syncthreads();
+                if (chunk * 3 + ky + 1 < n_phases) fetch_w(chunk * 3 + ky + 1);
+                else if (it + 1 < it_end) fetch_w(0);
+                if (ky == 0) {
+                    if (chunk + 1 < n_chunks) fetch_x(chunk + 1);
+                    else if (it + 1 < it_end) { setup_fetch(it + 1); fetch_x(0); }
+                }
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int kx = 0; kx < 3; ++kx) {
+                    bf16x8 a[2][3], bw[2][3];
 #pragma unroll
-                    for (int sp = 0; sp < 3; ++sp) {
-                        const uint4 t = w_s[b_base + ((kx * 3 + sp) * 2) * CO_BLK + n * 32];
-                        bw[n][sp] = *reinterpret_cast<const bf16x8*>(&t);
-                    }
-            // smallest partial products first; consecutive MFMAs go to different accumulators
-            constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+                    for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
+                        for (int sp = 0; sp < 3; ++sp) {
+                            const uint4 t = in_s[a_base + (sp * TL::IR + m * 2 + ky) * TL::ROW16 + kx];
+                            a[m][sp] = *reinterpret_cast<const bf16x8*>(&t);
+                        }
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][TI[t]], bw[n][TJ[t]], acc[m][n], 0, 0, 0);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) {
+                            const uint4 t = w_s[b_base + ((kx * 3 + sp) * 2) * CO_BLK + n * 32];
+                            bw[n][sp] = *reinterpret_cast<const bf16x8*>(&t);
+                        }
+                    // smallest partial products first; consecutive MFMAs go to different accumulators
+                    constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][TI[t]], bw[n][TJ[t]], acc[m][n], 0, 0, 0);
+                }
             }
         }
-    }
 
-    // ---- epilogue (same lane layout as conv.hip): registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h
-    const int py0 = y0 >> 1, px0 = x0 >> 1;
-    float* out_s = reinterpret_cast<float*>(in_raw);
-    if (amax == nullptr && (Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
-        __syncthreads();
+        // ---- epilogue (same lane layout as conv.hip): registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h
+        const int py0 = y0 >> 1, px0 = x0 >> 1;
+        if (amax == nullptr && (Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
+            // out_s was last read before the first barrier of this tile's first phase: free to overwrite
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float bv = bias[cb * CO_BLK + n * 32 + i];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
+                                              fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
+                        out_s[(n * 32 + i) * 65 + (wy * 2 + m) * PC + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
+                    }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < CO_BLK * 16; idx += 256) {
+                constexpr int XG = PC / 4;
+                const int x4 = idx % XG, py = (idx / XG) % PR, co_l = idx >> 4;
+                const float* sp = &out_s[co_l * 65 + py * PC + 4 * x4];
+                *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * CO_BLK + co_l) * Hp + py0 + py) * Wp + px0 + 4 * x4) =
+                    make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const float bv = bias[cb * CO_BLK + n * 32 + i];
+            const int co = cb * CO_BLK + n * 32 + i;
+            if (co >= Cout) continue;
+            const float bv = bias[co];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
+                const int py = py0 + wy * 2 + m;
+                if (py >= Hp) continue;
+                const size_t rowoff = (((size_t)b * Cout + co) * Hp + py) * Wp;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
-                                          fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
-                    out_s[(n * 32 + i) * 65 + (wy * 2 + m) * PC + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
-                }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < CO_BLK * 16; idx += 256) {
-            constexpr int XG = PC / 4;
-            const int x4 = idx % XG, py = (idx / XG) % PR, co_l = idx >> 4;
-            const float* sp = &out_s[co_l * 65 + py * PC + 4 * x4];
-            *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * CO_BLK + co_l) * Hp + py0 + py) * Wp + px0 + 4 * x4) =
-                make_float4(sp[0], sp[1], sp[2], sp[3]);
-        }
-        return;
-    }
+                    const int px = px0 + wx * 8 + 2 * q + h;
+                    float best = acc[m][n][4 * q];
+                    int bi = 0;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int co = cb * CO_BLK + n * 32 + i;
-        if (co >= Cout) continue;
-        const float bv = bias[co];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int py = py0 + wy * 2 + m;
-            if (py >= Hp) continue;
-            const size_t rowoff = (((size_t)b * Cout + co) * Hp + py) * Wp;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int px = px0 + wx * 8 + 2 * q + h;
-                float best = acc[m][n][4 * q];
-                int bi = 0;
-#pragma unroll
-                for (int e = 1; e < 4; ++e)
-                    if (acc[m][n][4 * q + e] > best) { best = acc[m][n][4 * q + e]; bi = e; }
-                if (px < Wp) {
-                    y[rowoff + px] = fmaxf(best + bv, 0.f);
-                    if (amax) amax[rowoff + px] = (unsigned char)bi;
+                    for (int e = 1; e < 4; ++e)
+                        if (acc[m][n][4 * q + e] > best) { best = acc[m][n][4 * q + e]; bi = e; }
+                    if (px < Wp) {
+                        y[rowoff + px] = fmaxf(best + bv, 0.f);
+                        if (amax) amax[rowoff + px] = (unsigned char)bi;
+                    }
                 }
             }
         }
@@ -467,11 +485,18 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     }
     const int tr = (4 / wx) * 4, tc = wx * 16;
     const int tiles_x = i2l_cdiv(cols, tc), tiles_y = i2l_cdiv(rows, tr);
-    if ((long long)tiles_x * tiles_y > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
-    dim3 grid(co_blocks, tiles_x * tiles_y, B);
+    // one resident round: 2 workgroups per CU x 256 CUs, each walking items_per_wg consecutive tiles
+    const int tiles_per_img = tiles_x * tiles_y;
+    const long long n_items_ll = (long long)tiles_per_img * B;
+    if (n_items_ll > 0x7fffffffll) return I2L_ERR_UNSUPPORTED;
+    const int n_items = (int)n_items_ll;
+    int items_per_wg = (int)((n_items_ll * co_blocks + 511) / 512);
+    if (items_per_wg < 1) items_per_wg = 1;
+    while (i2l_cdiv(n_items, items_per_wg) > 65535) ++items_per_wg;
+    dim3 grid(co_blocks, i2l_cdiv(n_items, items_per_wg));
 #define I2L_LAUNCH3(WXV)                                                                                              \
     hipLaunchKernelGGL(conv3x3_bf16x3_kernel<WXV>, grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, amax, Cin, H, W, \
-                       Cout, Hp, Wp, tiles_x, n_chunks)
+                       Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg)
     if (wx == 2) I2L_LAUNCH3(2);
     else if (wx == 1) I2L_LAUNCH3(1);
     else I2L_LAUNCH3(4);
