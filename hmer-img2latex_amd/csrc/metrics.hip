@@ -1,0 +1,164 @@
+// Sequence metrics of the evaluation loop on the device (reference img2latex/training/metrics.py):
+// per (prediction, target) pair the INTEGER statistics -- Levenshtein distance table corner (:49-94), clipped n-gram
+// match counts of BLEU-n (:97-181), token_list_accuracy counts (:241-277) -- and masked_accuracy's argmax / compare /
+// mask counts over a (rows, V) logits matrix (:226-238), so neither the id lists nor the (B,T,V) logits travel to the
+// host per step.  The float formulas on top (similarity = 1 - d / max_len, geometric mean, brevity penalty) are a few
+// float64 operations per pair and stay in the host wrapper, written exactly as the reference writes them.
+#include "common.h"
+
+namespace {
+
+constexpr int MT = 256;
+
+// One workgroup per pair.  LDS: a[R] | b[C] | three anti-diagonals of the distance table (C+1 each) | counters.
+__global__ __launch_bounds__(MT) void sequence_metrics_kernel(const int32_t* __restrict__ pred, const int32_t* __restrict__ pred_len,
+                                                              int pred_stride, const int32_t* __restrict__ tgt,
+                                                              const int32_t* __restrict__ tgt_len, int tgt_stride, int max_len,
+                                                              int max_n, int pad_id, int32_t* __restrict__ lev_out,
+                                                              int32_t* __restrict__ match_out, int32_t* __restrict__ tla_out) {
+    extern __shared__ int sm[];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int R = min(max(pred_len[pair], 0), max_len), C = min(max(tgt_len[pair], 0), max_len);
+    int* a = sm;                       // sequence_one = prediction (rows of the table)
+    int* b = a + max_len;              // sequence_two = target (columns)
+    int* dg = b + max_len;             // 3 x (max_len + 1)
+    int* cnt = dg + 3 * (max_len + 1); // [0..3] n-gram matches, [4] correct, [5] non-pad
+    for (int i = tid; i < R; i += MT) a[i] = pred[(size_t)pair * pred_stride + i];
+    for (int i = tid; i < C; i += MT) b[i] = tgt[(size_t)pair * tgt_stride + i];
+    if (tid < 6) cnt[tid] = 0;
+    __syncthreads();
+
+    // ---- Levenshtein (metrics.py:63-83): cell (r, c) on anti-diagonal d = r + c; equal tokens copy the diagonal
+    // neighbour, otherwise 1 + min(up, left, diagonal) -- the reference's recurrence, not a generic edit distance
+    int* p2 = dg;
+    int* p1 = dg + (max_len + 1);
+    int* cur = dg + 2 * (max_len + 1);
+    for (int d = 0; d <= R + C; ++d) {
+        for (int c = tid; c <= C; c += MT) {
+            const int r = d - c;
+            if (r < 0 || r > R) continue;
+            int v;
+            if (r == 0) v = c;
+            else if (c == 0) v = r;
+            else if (a[r - 1] == b[c - 1]) v = p2[c - 1];
+            else v = 1 + min(min(p1[c], p1[c - 1]), p2[c - 1]);
+            cur[c] = v;
+        }
+        __syncthreads();
+        int* t = p2; p2 = p1; p1 = cur; cur = t;
+    }
+    if (tid == 0) lev_out[pair] = p1[C];           // p1 = the last diagonal written
+
+    // ---- BLEU-n clipped matches (metrics.py:136-160): sum over DISTINCT generated n-grams of min(count in the
+    // prediction, count in the target); thread i owns the n-gram starting at i and counts it iff it is its first occurrence
+    for (int g = 1; g <= max_n; ++g) {
+        const int ng = R - g + 1, nt = C - g + 1;
+        int local = 0;
+        if (ng > 0 && nt > 0) {
+            for (int i = tid; i < ng; i += MT) {
+                bool first = true;
+                int cg = 0, ct = 0;
+                for (int j = 0; j < ng; ++j) {
+                    bool eq = true;
+                    for (int k = 0; k < g; ++k) eq = eq && a[j + k] == a[i + k];
+                    cg += eq ? 1 : 0;
+                    if (eq && j < i) first = false;
+                }
+                for (int j = 0; j < nt; ++j) {
+                    bool eq = true;
+                    for (int k = 0; k < g; ++k) eq = eq && b[j + k] == a[i + k];
+                    ct += eq ? 1 : 0;
+                }
+                if (first) local += min(cg, ct);
+            }
+        }
+        if (local) atomicAdd(&cnt[g - 1], local);
+    }
+    // ---- token_list_accuracy (metrics.py:259-274): positions below the shorter length, padding targets ignored
+    {
+        const int ml = min(R, C);
+        int correct = 0, nonpad = 0;
+        for (int i = tid; i < ml; i += MT) {
+            const bool np = b[i] != pad_id;
+            nonpad += np ? 1 : 0;
+            correct += (np && a[i] == b[i]) ? 1 : 0;
+        }
+        if (correct) atomicAdd(&cnt[4], correct);
+        if (nonpad) atomicAdd(&cnt[5], nonpad);
+    }
+    __syncthreads();
+    if (tid < 4) match_out[(size_t)pair * 4 + tid] = tid < max_n ? cnt[tid] : 0;
+    if (tid < 2 && tla_out) tla_out[(size_t)pair * 2 + tid] = cnt[4 + tid];
+}
+
+// masked_accuracy (metrics.py:226-238): one wave per row: first-index arg max over V, compare, mask; integer counts.
+__global__ __launch_bounds__(MT) void masked_accuracy_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                             long rows, int V, long pad_id,
+                                                             unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * (MT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (MT / 64);
+    unsigned long long correct = 0, total = 0;
+    for (long row = wave0; row < rows; row += nwaves) {
+        const float* p = logits + (size_t)row * V;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = lane; v < V; v += 64) {
+            const float x = p[v];
+            if (x > bv) { bv = x; bi = v; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            const int64_t t = targets[row];
+            if (t != pad_id) {
+                ++total;
+                if ((int64_t)bi == t) ++correct;
+            }
+        }
+    }
+    if (lane == 0 && (correct | total)) {
+        atomicAdd(&out[0], correct);
+        atomicAdd(&out[1], total);
+    }
+}
+
+size_t metrics_lds(int max_len) { return ((size_t)2 * max_len + 3 * ((size_t)max_len + 1) + 8) * sizeof(int); }
+
+}  // namespace
+
+extern "C" int i2l_sequence_metrics(const int32_t* pred, const int32_t* pred_len, int pred_stride, const int32_t* target,
+                                    const int32_t* target_len, int target_stride, int pairs, int max_len, int max_n,
+                                    int pad_id, int32_t* lev_out, int32_t* match_out, int32_t* tla_out,
+                                    i2l_stream_t stream) {
+    if (!pred || !pred_len || !target || !target_len || !lev_out || !match_out || pairs <= 0 || max_len < 0 || max_n < 1 ||
+        max_n > 4 || pred_stride < max_len || target_stride < max_len)
+        return I2L_ERR_ARG;
+    const size_t lds = metrics_lds(max_len);
+    if (lds > 160 * 1024) return I2L_ERR_UNSUPPORTED;       // sequences longer than ~8k tokens
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sequence_metrics_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return I2L_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sequence_metrics_kernel, dim3(pairs), dim3(MT), lds, i2l_s(stream), pred, pred_len, pred_stride, target,
+                       target_len, target_stride, max_len, max_n, pad_id, lev_out, match_out, tla_out);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+extern "C" int i2l_masked_accuracy(const float* logits, const int64_t* targets, int64_t rows, int vocab, int64_t pad_id,
+                                   uint64_t* correct_total_out, i2l_stream_t stream) {
+    if (!logits || !targets || !correct_total_out || rows <= 0 || vocab <= 0) return I2L_ERR_ARG;
+    hipStream_t s = i2l_s(stream);
+    if (hipMemsetAsync(correct_total_out, 0, 2 * sizeof(uint64_t), s) != hipSuccess) return I2L_ERR_LAUNCH;
+    long blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(masked_accuracy_kernel, dim3((unsigned)blocks), dim3(MT), 0, s, logits, targets, (long)rows, vocab,
+                       (long)pad_id, reinterpret_cast<unsigned long long*>(correct_total_out));
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}

@@ -267,6 +267,31 @@ int i2l_grad_clip_adam_step(float* params, const float* grads, float* exp_avg, f
                             float eps, float weight_decay, int step, void* workspace, size_t workspace_bytes,
                             float* stats_out, i2l_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Evaluation metrics (reference img2latex/training/metrics.py), SURVEY section 8(f)-4
+ * ---------------------------------------------------------------------- */
+
+/* Integer statistics of `pairs` (prediction, target) id sequences, one workgroup per pair:
+ *   lev_out[p]       the corner dist_tab[rows][cols] of levenshtein_distance's table, metrics.py:63-83
+ *                    (equal tokens copy the diagonal neighbour, otherwise 1 + min(up, left, diagonal))
+ *   match_out[p][g]  g = 0..3: sum over the DISTINCT (g+1)-grams of the prediction of
+ *                    min(count in prediction, count in target) -- bleu_n_score's matching_grams_sum,
+ *                    metrics.py:136-160; 0 for g >= max_n or when either sequence is shorter than g+1
+ *   tla_out[p][0..1] token_list_accuracy's (correct, non-pad) counts over the first min(len) positions,
+ *                    metrics.py:259-274; may be NULL
+ * pred (pairs, pred_stride) / target (pairs, target_stride) int32 rows, lengths clamped to [0, max_len].
+ * The float formulas on top (1 - d / max_len; precisions, geometric mean, brevity penalty) are host
+ * arithmetic in float64, exactly as the reference writes them (img2latex_amd/training/metrics.py). */
+int i2l_sequence_metrics(const int32_t* pred, const int32_t* pred_len, int pred_stride, const int32_t* target,
+                         const int32_t* target_len, int target_stride, int pairs, int max_len, int max_n,
+                         int pad_id, int32_t* lev_out, int32_t* match_out, int32_t* tla_out, i2l_stream_t stream);
+
+/* masked_accuracy, metrics.py:226-238 (trainer.py:391,526): over rows = B*T logits rows of `vocab` floats,
+ * correct_total_out[0] = #(argmax == target and target != pad), [1] = #(target != pad); first index wins
+ * ties.  The (B,T,V) logits never leave the device (the reference copies them to the host every step). */
+int i2l_masked_accuracy(const float* logits, const int64_t* targets, int64_t rows, int vocab, int64_t pad_id,
+                        uint64_t* correct_total_out, i2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

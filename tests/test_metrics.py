@@ -1,0 +1,93 @@
+"""Evaluation metrics (reference img2latex/training/metrics.py).
+
+CPU: the oracle restatement against the reference's golden outputs (tests/golden/metrics.npz).
+GPU: the HIP kernels (through the C ABI / the drop-in functions) against the oracle's integer statistics (exact)
+and against the reference's float outputs (exact: the float formulas are the reference's own float64 arithmetic)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN as GOLDEN_DIR
+import metrics_oracle as MO
+from img2latex_amd import synth
+
+PAD = 0
+
+
+def load():
+    d = np.load(f"{GOLDEN_DIR}/metrics.npz")
+    preds = [d["pred"][i, : d["pred_len"][i]].tolist() for i in range(len(d["pred_len"]))]
+    tgts = [d["tgt"][i, : d["tgt_len"][i]].tolist() for i in range(len(d["tgt_len"]))]
+    return d, preds, tgts
+
+
+def ma_inputs(d):
+    s1, s2, B, T, V = (int(x) for x in d["ma_seed"])
+    logits = np.round(synth.normal_like(s1, "logits", (B, T, V)) * 4.0).astype(np.float32) / 4.0
+    targets = synth.randint(s2, "targets", (B, T), 0, V).astype(np.int64)
+    return logits, targets
+
+
+def test_oracle_matches_reference_outputs():
+    d, preds, tgts = load()
+    for i, (p, t) in enumerate(zip(preds, tgts)):
+        assert MO.levenshtein_distance(p, t) == d["lev"][i], i
+        for n in (1, 2, 3, 4):
+            assert MO.bleu_n_score(p, t, n) == d["bleu"][i, n - 1], (i, n)
+    cm = MO.calculate_metrics(preds, tgts)
+    assert cm["bleu"] == d["calc"][0] and cm["levenshtein"] == d["calc"][1] and cm["batch_size"] == d["calc"][2]
+    assert MO.token_list_accuracy(preds, tgts, PAD) == tuple(d["tla"].tolist())
+    logits, targets = ma_inputs(d)
+    assert MO.masked_accuracy(logits, targets, PAD) == tuple(d["ma"].tolist())
+
+
+@pytest.mark.gpu
+def test_kernel_statistics_and_scores_vs_reference():
+    from img2latex_amd.training import metrics as M
+    d, preds, tgts = load()
+    st = M.sequence_statistics(preds, tgts, 4, PAD)
+    for i, (p, t) in enumerate(zip(preds, tgts)):
+        assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), i
+        assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), i
+    cm = M.calculate_metrics(preds, tgts)
+    assert cm["bleu"] == d["calc"][0] and cm["levenshtein"] == d["calc"][1] and cm["batch_size"] == int(d["calc"][2])
+    assert M.token_list_accuracy(preds, tgts, PAD) == tuple(d["tla"].tolist())
+    for i in (0, 1, 2, 5, 9, 13, 17, 18):                                 # single-pair entry points
+        assert M.levenshtein_distance(preds[i], tgts[i]) == d["lev"][i]
+        for n in (1, 2, 3, 4):
+            assert M.bleu_n_score(preds[i], tgts[i], n) == d["bleu"][i, n - 1]
+
+
+@pytest.mark.gpu
+def test_masked_accuracy_on_device():
+    from img2latex_amd.training import metrics as M
+    d, _, _ = load()
+    logits, targets = ma_inputs(d)
+    dev = torch.device("cuda:0")
+    got = M.masked_accuracy(torch.from_numpy(logits).to(dev), torch.from_numpy(targets).to(dev), PAD)
+    assert got == tuple(d["ma"].tolist())
+    # a full-size training batch: (64, 149, 512) logits never leave the device; checked against torch on the device
+    g = torch.Generator(device="cpu").manual_seed(3)
+    lg = torch.randn(64, 149, 512, generator=g).to(dev)
+    tg = torch.randint(0, 512, (64, 149), generator=g).to(dev)
+    c, t = M.masked_accuracy(lg, tg, PAD)
+    mask = tg.ne(PAD)
+    assert t == int(mask.sum()) and c == int((lg.argmax(-1).eq(tg) & mask).sum())
+
+
+@pytest.mark.gpu
+def test_device_id_matrices_and_long_sequences():
+    """Ids straight from a decode kernel layout ((B, steps) int32 + lengths), sequences longer than a workgroup."""
+    from img2latex_amd.training import metrics as M
+    dev = torch.device("cuda:0")
+    B, W = 9, 700
+    P = synth.randint(31, "p", (B, W), 1, 6).astype(np.int32)
+    T = synth.randint(32, "t", (B, W), 1, 6).astype(np.int32)
+    pl = np.array([0, 1, 50, 255, 256, 257, 513, 699, 700], np.int32)
+    tl = np.array([3, 0, 64, 300, 256, 2, 700, 650, 700], np.int32)
+    st = M.device_sequence_statistics(torch.from_numpy(P).to(dev), torch.from_numpy(pl).to(dev),
+                                      torch.from_numpy(T).to(dev), torch.from_numpy(tl).to(dev), 4, PAD)
+    for i in range(B):
+        p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
+        assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), i
+        assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), i
