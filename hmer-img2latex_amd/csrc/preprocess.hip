@@ -1,0 +1,165 @@
+// Image preprocessing of the inference / data path on the device (reference img2latex/data/utils.py:18-90 `load_image`
+// after PIL has decoded the file, with data/transforms.py:26-56 `ResizeWithAspectRatio`): mode conversion, LANCZOS
+// resize to the target height (aspect kept), right-pad / centre-crop to the target width, /255 and normalisation,
+// for a ragged batch of uint8 images in ONE pair of launches.  The resize is Pillow's (libImaging/Resample.c, 8 bits
+// per channel): separable, horizontal pass first into an 8-bit intermediate, per-output-pixel normalised Lanczos-3
+// weights in 22-bit fixed point, int32 accumulation from 2^21, arithmetic shift, clamp.  The weights are computed on
+// the HOST in double precision with libm's sin -- i2l_lanczos_coeffs below, the same arithmetic Pillow runs -- so the
+// device work is pure integer and the result is bit-identical to the reference's.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int PREC = 32 - 8 - 2;
+
+double sinc_filter(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * M_PI;
+    return sin(x) / x;
+}
+double lanczos_filter(double x) {
+    if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+    return 0.0;
+}
+
+// value of converted-mode pixel (y, x, band c) of the source image: utils.py:45-49 img.convert("L" / "RGB")
+__device__ __forceinline__ int src_px(const uint8_t* __restrict__ img, int w, int src_c, int out_c, int y, int x, int c) {
+    const size_t p = ((size_t)y * w + x) * src_c;
+    if (src_c == out_c) return img[p + c];
+    if (src_c == 3) return (img[p] * 19595 + img[p + 1] * 38470 + img[p + 2] * 7471 + 0x8000) >> 16;   // RGB -> L
+    return img[p];                                                                                        // L -> RGB
+}
+__device__ __forceinline__ int clip8(int acc) { return min(max(acc >> PREC, 0), 255); }
+
+// horizontal pass: tmp[row][xx][c] for rows ybox_first .. ybox_first + tmp_rows
+__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ pixels, const i2l_resize_plan* __restrict__ plans,
+                                                       const int32_t* __restrict__ tables, uint8_t* __restrict__ ws, int out_c) {
+    const i2l_resize_plan pl = plans[blockIdx.y];
+    if (!pl.need_h) return;
+    const long total = (long)pl.tmp_rows * pl.new_w;
+    const uint8_t* img = pixels + pl.src_offset;
+    uint8_t* tmp = ws + pl.tmp_offset;
+    const int32_t* bh = tables + pl.bh_offset;
+    const int32_t* kh = tables + pl.kh_offset;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int row = (int)(idx / pl.new_w), xx = (int)(idx - (long)row * pl.new_w);
+        const int xmin = bh[2 * xx], n = bh[2 * xx + 1];
+        const int32_t* k = kh + (size_t)xx * pl.kh_ksize;
+        for (int c = 0; c < out_c; ++c) {
+            int acc = 1 << (PREC - 1);
+            for (int x = 0; x < n; ++x) acc += src_px(img, pl.src_w, pl.src_c, out_c, pl.ybox_first + row, xmin + x, c) * k[x];
+            tmp[((size_t)row * pl.new_w + xx) * out_c + c] = (uint8_t)clip8(acc);
+        }
+    }
+}
+
+// vertical pass + pad / crop + float conversion: out[b][c][y][x]
+__global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __restrict__ pixels, const i2l_resize_plan* __restrict__ plans,
+                                                            const int32_t* __restrict__ tables, const uint8_t* __restrict__ ws,
+                                                            int out_c, int out_h, int out_w, int normalize, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const i2l_resize_plan pl = plans[b];
+    const uint8_t* img = pixels + pl.src_offset;
+    const uint8_t* tmp = ws + pl.tmp_offset;
+    const int32_t* bv = tables + pl.bv_offset;
+    const int32_t* kv = tables + pl.kv_offset;
+    const int left = pl.new_w > out_w ? (pl.new_w - out_w) / 2 : 0;        // transforms.py:50-55 centre crop
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)out_h * out_w; idx += (long)gridDim.x * 256) {
+        const int y = (int)(idx / out_w), x = (int)(idx - (long)y * out_w);
+        const int xs = x + left;
+        for (int c = 0; c < out_c; ++c) {
+            int v;
+            if (xs >= pl.new_w) {
+                v = (out_c == 1 || c == 0) ? 255 : 0;      // Image.new(mode, size, 255): white for L, (255,0,0) for RGB
+            } else if (pl.need_v) {
+                const int y0 = bv[2 * y], n = bv[2 * y + 1];                // y0 already relative to the intermediate image
+                const int32_t* k = kv + (size_t)y * pl.kv_ksize;
+                int acc = 1 << (PREC - 1);
+                if (pl.need_h)
+                    for (int j = 0; j < n; ++j) acc += tmp[((size_t)(y0 + j) * pl.new_w + xs) * out_c + c] * k[j];
+                else
+                    for (int j = 0; j < n; ++j) acc += src_px(img, pl.src_w, pl.src_c, out_c, y0 + j, xs, c) * k[j];
+                v = clip8(acc);
+            } else {
+                v = pl.need_h ? tmp[((size_t)y * pl.new_w + xs) * out_c + c] : src_px(img, pl.src_w, pl.src_c, out_c, y, xs, c);
+            }
+            float t = __fdiv_rn((float)v, 255.0f);                          // utils.py:68
+            if (normalize) {
+                if (out_c == 1) t = __fsub_rn(__fmul_rn(t, 2.0f), 1.0f);   // utils.py:74
+                else t = __fdiv_rn(__fsub_rn(t, mean[c]), stdv[c]);         // utils.py:77-79
+            }
+            out[(((size_t)b * out_c + c) * out_h + y) * out_w + x] = t;
+        }
+    }
+}
+
+}  // namespace
+
+// ---- host: Pillow's precompute_coeffs + normalize_coeffs_8bpc for the LANCZOS filter over the full source range
+extern "C" int i2l_lanczos_ksize(int in_size, int out_size) {
+    if (in_size <= 0 || out_size <= 0) return 0;
+    double filterscale = (double)((float)in_size - 0.0f) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    return (int)ceil(3.0 * filterscale) * 2 + 1;
+}
+
+extern "C" int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out) {
+    if (in_size <= 0 || out_size <= 0 || !bounds_out || !kk_out) return I2L_ERR_ARG;
+    const float in0 = 0.0f, in1 = (float)in_size;
+    double filterscale, scale;
+    filterscale = scale = (double)(in1 - in0) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 3.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = in0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double k[512];
+        if (xmax > 512) return I2L_ERR_UNSUPPORTED;           // down-scaling by more than ~80x
+        int x;
+        for (x = 0; x < xmax; ++x) {
+            const double w = lanczos_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        int32_t* kk = kk_out + (size_t)xx * ksize;
+        for (x = 0; x < xmax; ++x) {
+            if (ww != 0.0) k[x] /= ww;
+            kk[x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << PREC)) : (int)(0.5 + k[x] * (1 << PREC));
+        }
+        for (; x < ksize; ++x) kk[x] = 0;
+        bounds_out[2 * xx] = xmin;
+        bounds_out[2 * xx + 1] = xmax;
+    }
+    return I2L_OK;
+}
+
+extern "C" int i2l_preprocess_images(const uint8_t* pixels, const i2l_resize_plan* plans, const int32_t* tables, int n,
+                                     int max_tmp_px, int out_c, int out_h, int out_w, int normalize, void* workspace,
+                                     float* out, i2l_stream_t stream) {
+    if (!pixels || !plans || !tables || !out || n <= 0 || (out_c != 1 && out_c != 3) || out_h <= 0 || out_w <= 0 || n > 65535)
+        return I2L_ERR_ARG;
+    if (max_tmp_px > 0 && !workspace) return I2L_ERR_WORKSPACE;
+    hipStream_t s = i2l_s(stream);
+    if (max_tmp_px > 0) {
+        int bx = (max_tmp_px + 255) / 256;
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(resize_h_kernel, dim3(bx, n), dim3(256), 0, s, pixels, plans, tables, static_cast<uint8_t*>(workspace), out_c);
+        I2L_CHECK_LAUNCH();
+    }
+    int bx = (out_h * out_w + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(resize_v_norm_kernel, dim3(bx, n), dim3(256), 0, s, pixels, plans, tables,
+                       static_cast<const uint8_t*>(workspace), out_c, out_h, out_w, normalize, out);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}

@@ -92,6 +92,10 @@ _SIGNATURES.update({
     "i2l_sequence_metrics": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "i2l_masked_accuracy": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_void_p]),
+    "i2l_lanczos_ksize": (c_int, [c_int, c_int]),
+    "i2l_lanczos_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    "i2l_preprocess_images": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p, c_void_p]),
 })
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _LIB: Optional[ctypes.CDLL] = None

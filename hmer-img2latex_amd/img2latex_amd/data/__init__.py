@@ -1,0 +1,3 @@
+from .preprocess import batch_convert_for_resnet, load_image, preprocess_batch
+
+__all__ = ["load_image", "preprocess_batch", "batch_convert_for_resnet"]

@@ -292,6 +292,41 @@ int i2l_sequence_metrics(const int32_t* pred, const int32_t* pred_len, int pred_
 int i2l_masked_accuracy(const float* logits, const int64_t* targets, int64_t rows, int vocab, int64_t pad_id,
                         uint64_t* correct_total_out, i2l_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Image preprocessing (reference img2latex/data/utils.py:18-90, data/transforms.py:26-56), SURVEY section 8(f)-3
+ * ---------------------------------------------------------------------- */
+
+/* Host helpers (no GPU work): Pillow's LANCZOS coefficient tables for resampling `in_size` source samples to
+ * `out_size` (libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc over the full source range, double
+ * precision, libm sin): bounds_out (out_size, 2) = first source sample and count, kk_out (out_size, ksize) = 22-bit
+ * fixed-point weights, ksize = i2l_lanczos_ksize(in_size, out_size). */
+int i2l_lanczos_ksize(int in_size, int out_size);
+int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out);
+
+/* One image of a ragged batch.  Offsets index `pixels` (bytes), `tables` (int32 elements) and the workspace
+ * (bytes).  bv bounds must already be relative to the intermediate image when need_h (Resample.c: "Shift bounds
+ * for vertical pass"). */
+typedef struct i2l_resize_plan {
+    int64_t src_offset;            /* first byte of the uint8 image: (src_h, src_w) or (src_h, src_w, 3) interleaved */
+    int64_t tmp_offset;            /* intermediate image (tmp_rows, new_w, out_c) uint8 in the workspace             */
+    int64_t bh_offset, kh_offset;  /* horizontal bounds / weights                                                    */
+    int64_t bv_offset, kv_offset;  /* vertical bounds / weights                                                      */
+    int32_t src_h, src_w, src_c;
+    int32_t new_w;                 /* int(round(out_h * src_w / src_h)), transforms.py:33-36                         */
+    int32_t ybox_first, tmp_rows;  /* source rows the vertical pass needs                                            */
+    int32_t need_h, need_v;        /* new_w != src_w, out_h != src_h                                                 */
+    int32_t kh_ksize, kv_ksize;
+} i2l_resize_plan;
+
+/* load_image for n decoded images: convert("L"/"RGB") -> LANCZOS resize to (new_w, out_h) -> right-pad (white for
+ * 1 channel; Pillow's integer colour 255 = (255,0,0) for 3 channels, as the reference executes) or centre-crop to
+ * out_w -> /255 -> [-1,1] (1 channel) or ImageNet mean/std (3 channels) when `normalize`.  out (n, out_c, out_h,
+ * out_w) fp32, bit-identical to the reference's tensor.  plans / tables live in device memory; max_tmp_px = the
+ * largest tmp_rows*new_w over the batch (0 when no image needs a horizontal pass). */
+int i2l_preprocess_images(const uint8_t* pixels, const i2l_resize_plan* plans, const int32_t* tables, int n,
+                          int max_tmp_px, int out_c, int out_h, int out_w, int normalize, void* workspace,
+                          float* out, i2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

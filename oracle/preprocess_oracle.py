@@ -1,0 +1,150 @@
+"""CPU restatement of the reference's image preprocessing -- TEST INFRASTRUCTURE (tests/, smoke(), cpu_baseline only).
+
+Path: img2latex/data/utils.py:18-90 `load_image` (after PIL has decoded the file) =
+  mode conversion (utils.py:45-49) -> `ResizeWithAspectRatio` (data/transforms.py:26-56: LANCZOS resize to the
+  target height keeping the aspect ratio, then right-pad with white or centre-crop to the target width) ->
+  float / 255 -> [-1,1] (1 channel) or ImageNet mean/std (3 channels) (utils.py:58-80).
+
+The resize itself lives in a third-party dependency of the reference: Pillow (pinned here: 12.2.0, the version in
+this image; `Image.resize(..., Resampling.LANCZOS)` -> libImaging/Resample.c).  Its published algorithm for 8-bit
+images is restated below: separable two-pass convolution, horizontal pass first into an 8-bit intermediate image,
+double-precision Lanczos-3 coefficients normalised per output pixel and rounded to 22-bit fixed point, accumulation
+in int32 from 2^21, arithmetic shift, clamp to [0,255].  Pinned: tests/golden/preprocess.npz holds the outputs of
+the real `load_image` (reference + Pillow) for generated images; tests/test_preprocess.py checks bit equality.
+"""
+import math
+from typing import Tuple
+
+import numpy as np
+
+PRECISION_BITS = 32 - 8 - 2            # Resample.c
+LANCZOS_SUPPORT = 3.0
+
+
+def _sinc(x: float) -> float:
+    if x == 0.0:
+        return 1.0
+    x = x * math.pi
+    return math.sin(x) / x
+
+
+def _lanczos(x: float) -> float:
+    if -3.0 <= x < 3.0:
+        return _sinc(x) * _sinc(x / 3)
+    return 0.0
+
+
+def precompute_coeffs(in_size: int, in0: float, in1: float, out_size: int):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc: (ksize, bounds (out,2) int, kk (out,ksize) int32)."""
+    scale = float(np.float32(in1) - np.float32(in0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = LANCZOS_SUPPORT * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = in0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [_lanczos((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        if ww != 0.0:
+            k = [w / ww for w in k]
+        for x, w in enumerate(k):
+            v = w * (1 << PRECISION_BITS)
+            kk[xx, x] = int(-0.5 + v) if w < 0 else int(0.5 + v)
+        bounds[xx] = (xmin, xmax)
+    return ksize, bounds, kk
+
+
+def _clip8(acc: np.ndarray) -> np.ndarray:
+    return np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def resize_lanczos_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """Image.resize((out_w, out_h), LANCZOS) for mode L (H,W) or RGB (H,W,3) uint8 (Image.py resize + Resample.c)."""
+    h, w = img.shape[:2]
+    if (w, h) == (out_w, out_h):
+        return img.copy()
+    src = img.reshape(h, w, -1).astype(np.int64)
+    need_h, need_v = out_w != w, out_h != h
+    _, bh, kh = precompute_coeffs(w, 0.0, float(w), out_w)
+    _, bv, kv = precompute_coeffs(h, 0.0, float(h), out_h)
+    ybox_first = int(bv[0, 0])
+    ybox_last = int(bv[out_h - 1, 0] + bv[out_h - 1, 1])
+    cur = src
+    if need_h:
+        bv = bv.copy()
+        bv[:, 0] -= ybox_first
+        rows = cur[ybox_first:ybox_last]
+        tmp = np.zeros((rows.shape[0], out_w, src.shape[2]), np.int64)
+        for xx in range(out_w):
+            x0, n = int(bh[xx, 0]), int(bh[xx, 1])
+            acc = (1 << (PRECISION_BITS - 1)) + np.tensordot(rows[:, x0:x0 + n, :], kh[xx, :n].astype(np.int64), axes=([1], [0]))
+            tmp[:, xx, :] = _clip8(acc)
+        cur = tmp
+    if need_v:
+        out = np.zeros((out_h, cur.shape[1], src.shape[2]), np.int64)
+        for yy in range(out_h):
+            y0, n = int(bv[yy, 0]), int(bv[yy, 1])
+            acc = (1 << (PRECISION_BITS - 1)) + np.tensordot(kv[yy, :n].astype(np.int64), cur[y0:y0 + n], axes=([0], [0]))
+            out[yy] = _clip8(acc)
+        cur = out
+    return cur.astype(np.uint8).reshape((out_h, out_w) + img.shape[2:])
+
+
+def convert_mode(img: np.ndarray, channels: int) -> np.ndarray:
+    """utils.py:45-49 `img.convert("L" / "RGB")` for uint8 L (H,W) / RGB (H,W,3) sources (Pillow Convert.c rgb2l / l2rgb)."""
+    if channels == 1 and img.ndim == 3:
+        r, g, b = (img[..., i].astype(np.int64) for i in range(3))
+        return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+    if channels == 3 and img.ndim == 2:
+        return np.repeat(img[..., None], 3, axis=2)
+    return img
+
+
+def resize_with_aspect_ratio(img: np.ndarray, target_h: int, target_w: int) -> np.ndarray:
+    """transforms.py:26-56 on a uint8 array."""
+    h, w = img.shape[:2]
+    new_w = int(round(target_h * (w / h)))
+    res = resize_lanczos_u8(img, new_w, target_h)
+    if new_w == target_w:
+        return res
+    if new_w < target_w:
+        # Image.new(mode, size, 255): for "RGB" the integer colour 255 is the packed pixel 0x000000FF = (255, 0, 0),
+        # so 3-channel images are padded with RED, not white (transforms.py:44-47 as executed by Pillow)
+        out = np.zeros((target_h, target_w) + img.shape[2:], np.uint8)
+        out[..., 0] = 255
+        if img.ndim == 2:
+            out[...] = 255
+        out[:, :new_w] = res
+        return out
+    left = (new_w - target_w) // 2
+    return res[:, left:left + target_w]
+
+
+def load_image_from_array(img: np.ndarray, img_size: Tuple[int, int], channels: int, normalize: bool = True) -> np.ndarray:
+    """utils.py:37-80 given the decoded uint8 image: (C, H, W) float32."""
+    img = convert_mode(img, channels)
+    img = resize_with_aspect_ratio(img, img_size[0], img_size[1])
+    if channels == 1:
+        t = img[None].astype(np.float32)
+    else:
+        t = np.transpose(img, (2, 0, 1)).astype(np.float32)
+    t = t / np.float32(255.0)
+    if normalize:
+        if channels == 1:
+            t = t * np.float32(2.0) - np.float32(1.0)
+        else:
+            mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(-1, 1, 1)
+            std = np.array([0.229, 0.224, 0.225], np.float32).reshape(-1, 1, 1)
+            t = (t - mean) / std
+    return t.astype(np.float32)

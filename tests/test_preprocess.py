@@ -1,0 +1,75 @@
+"""Image preprocessing (reference data/utils.py:18-110, data/transforms.py:26-56; Pillow 12.2 LANCZOS).
+
+CPU: the oracle restatement and the library's host coefficient helper against the reference's golden outputs.
+GPU: the HIP kernels, bit-identical float32 tensors for the whole ragged batch."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+import preprocess_oracle as PO
+from img2latex_amd import _lib, synth
+
+
+def make_image(seed, h, w, c):          # the generator of tests/golden/make_golden_preprocess.py
+    base = synth.uniform(seed, "img", (h, w, c), 0.0, 1.0)
+    strokes = (synth.uniform(seed + 1, "mask", (h, w, 1), 0.0, 1.0) < 0.18)
+    img = np.where(strokes, base * 90.0, 200.0 + base * 55.0)
+    return np.clip(np.round(img), 0, 255).astype(np.uint8).reshape((h, w) if c == 1 else (h, w, 3))
+
+
+def cases():
+    d = np.load(f"{GOLDEN}/preprocess.npz")
+    return d, [tuple(r) for r in d["cases"].tolist()]
+
+
+def test_oracle_bit_exact_vs_reference():
+    d, cs = cases()
+    for i, (h, w, c, th, tw, oc) in enumerate(cs):
+        got = PO.load_image_from_array(make_image(1000 + 10 * i, h, w, c), (th, tw), oc, True)
+        assert got.dtype == np.float32 and got.shape == d[f"out{i}"].shape
+        assert np.array_equal(got, d[f"out{i}"]), i
+    for i in (0, 5):
+        h, w, c, th, tw, oc = cs[i]
+        assert np.array_equal(PO.load_image_from_array(make_image(1000 + 10 * i, h, w, c), (th, tw), oc, False), d[f"raw{i}"])
+
+
+def test_host_coefficients_equal_oracle():
+    """i2l_lanczos_coeffs (C, libm) == the oracle's restatement of Pillow's precompute_coeffs (Python, libm)."""
+    L = _lib.lib()
+    for (a, b) in [(150, 240), (500, 160), (2400, 768), (64, 64), (40, 64), (200, 64), (23, 60), (17, 32), (300, 14)]:
+        ks, bo, ko = PO.precompute_coeffs(a, 0.0, float(a), b)
+        assert L.i2l_lanczos_ksize(a, b) == ks
+        bounds = np.zeros((b, 2), np.int32)
+        kk = np.zeros((b, ks), np.int32)
+        assert L.i2l_lanczos_coeffs(a, b, bounds.ctypes.data, kk.ctypes.data) == 0
+        assert np.array_equal(bounds, bo) and np.array_equal(kk, ko), (a, b)
+
+
+@pytest.mark.gpu
+def test_device_preprocessing_bit_exact():
+    from img2latex_amd.data import preprocess_batch
+    d, cs = cases()
+    groups = {}
+    for i, (h, w, c, th, tw, oc) in enumerate(cs):
+        groups.setdefault((th, tw, oc), []).append(i)
+    for (th, tw, oc), idx in groups.items():                       # one ragged batch per output configuration
+        imgs = [make_image(1000 + 10 * i, *cs[i][:3]) for i in idx]
+        out = preprocess_batch(imgs, (th, tw), oc, True).cpu().numpy()
+        for j, i in enumerate(idx):
+            assert np.array_equal(out[j], d[f"out{i}"]), (i, cs[i])
+    raw = preprocess_batch([make_image(1000, *cs[0][:3])], cs[0][3:5], cs[0][5], False).cpu().numpy()[0]
+    assert np.array_equal(raw, d["raw0"])
+
+
+@pytest.mark.gpu
+def test_device_preprocessing_full_batch_vs_oracle():
+    """256 page-like images of assorted sizes -> (256, 3, 64, 320): every pixel equal to the oracle's."""
+    from img2latex_amd.data import preprocess_batch
+    sizes = [(30 + (7 * k) % 90, 80 + (53 * k) % 700, 1 + 2 * (k % 2)) for k in range(256)]
+    imgs = [make_image(5000 + k, h, w, c) for k, (h, w, c) in enumerate(sizes)]
+    out = preprocess_batch(imgs, (64, 320), 3, True)
+    assert out.shape == (256, 3, 64, 320) and out.is_cuda
+    got = out.cpu().numpy()
+    for k in range(0, 256, 17):
+        assert np.array_equal(got[k], PO.load_image_from_array(imgs[k], (64, 320), 3, True)), k
