@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--pipe-rows", type=int, default=2, help="decode rows per workgroup in the pipelined region")
     ap.add_argument("--pipe-decoders", type=int, default=1, help="decode streams in the pipelined region")
     ap.add_argument("--pipe-depth", type=int, default=2, help="batches in flight in the pipelined region")
-    ap.add_argument("--mode", choices=["greedy", "beam", "train", "resnet"], default="greedy",
+    ap.add_argument("--mode", choices=["greedy", "beam", "train", "resnet", "preprocess", "metrics"], default="greedy",
                     help="greedy = the headline (BASELINE configs[1]); beam = configs[2] (128 images x k=5, attention); "
                          "train = configs[3] (teacher-forced fwd+bwd+CE+clip+Adam, 64 samples/GPU, RCCL all-reduce); "
                          "resnet = configs[4] (ResNet50 encoder in bf16 + greedy decode, batch 256)")
@@ -322,6 +322,56 @@ def extra_modes(args, world, rank, dev, dist):
         conf = {"workload": "resnet50_lstm greedy (BASELINE configs[4])", "batch_per_gpu": Bn, "image": "3x64x320",
                 "decode_steps": T, "encoder_dtype": "bf16 (fp32 accumulate)", "encoder_ms": enc_ms,
                 "encoder_gflop": round(gflop, 1)}
+    elif args.mode == "preprocess":
+        # load_image after decoding for a ragged batch of page-like uint8 images -> (B, 3, 64, 320)
+        from img2latex_amd.data import preprocess_batch
+        Bn = args.batch
+        sizes = [(30 + (7 * k) % 90, 80 + (53 * k) % 700, 1 + 2 * (k % 2)) for k in range(Bn)]
+        imgs = []
+        for k, (h, w, c) in enumerate(sizes):
+            base = synth.uniform(5000 + k + 1000 * rank, "img", (h, w, c), 0.0, 255.0)
+            imgs.append(np.round(base).astype(np.uint8).reshape((h, w) if c == 1 else (h, w, 3)))
+        out = [None]
+
+        def one_step():
+            out[0] = preprocess_batch(imgs, (64, 320), 3, True)
+        unit = lambda: float(Bn)
+        name = "preprocessed images/sec (convert + LANCZOS resize + pad/crop + normalise, host plan + upload included)"
+        conf = {"workload": "load_image tail for a ragged batch (SURVEY 8f-3)", "batch_per_gpu": Bn, "out": "3x64x320",
+                "unit": "images/s"}
+        if rank == 0:
+            from PIL import Image
+            t0 = time.perf_counter()
+            for a in imgs:                                  # the reference's CPU path: Pillow resize + numpy/torch tail
+                im = Image.fromarray(a, "L" if a.ndim == 2 else "RGB").convert("RGB")
+                nw = int(round(64 * (im.size[0] / im.size[1])))
+                im = im.resize((nw, 64), Image.Resampling.LANCZOS)
+                canvas = Image.new("RGB", (320, 64), 255)
+                canvas.paste(im.crop(((nw - 320) // 2, 0, (nw - 320) // 2 + 320, 64)) if nw > 320 else im, (0, 0))
+                t = torch.from_numpy(np.transpose(np.array(canvas), (2, 0, 1))).float() / 255.0
+                t = (t - torch.tensor([0.485, 0.456, 0.406]).view(-1, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(-1, 1, 1)
+            conf["cpu_baseline"] = {"value": round(Bn / (time.perf_counter() - t0), 1), "unit": "images/s", "cores": 1,
+                                    "kind": "reference-equivalent (Pillow 1 thread)", "sample": f"{Bn} images"}
+    elif args.mode == "metrics":
+        # calculate_metrics (BLEU-4 + Levenshtein) for a batch of decoded sequences
+        from img2latex_amd.training import metrics as M
+        Bn, T = args.batch, args.seq
+        preds = [synth.randint(900 + k, "p", (T - (k % 17),), 4, 64).tolist() for k in range(Bn)]
+        tgts = [synth.randint(901 + k, "t", (T - (k % 11),), 4, 64).tolist() for k in range(Bn)]
+        out = [None]
+
+        def one_step():
+            out[0] = M.calculate_metrics(preds, tgts)
+        unit = lambda: float(Bn)
+        name = "sequence pairs/sec (BLEU-4 + Levenshtein, list packing + upload included)"
+        conf = {"workload": "calculate_metrics (SURVEY 8f-4)", "pairs": Bn, "tokens_per_sequence": T, "unit": "pairs/s"}
+        if rank == 0:
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            import metrics_oracle as MO
+            t0 = time.perf_counter()
+            ref = MO.calculate_metrics(preds[:32], tgts[:32])
+            conf["cpu_baseline"] = {"value": round(32 / (time.perf_counter() - t0), 1), "unit": "pairs/s", "cores": 1,
+                                    "kind": "port", "sample": "32 pairs"}
     else:
         Bt, T = 64, 150
         cfg = synth.model_config(dropout=0.1)
@@ -361,7 +411,7 @@ def extra_modes(args, world, rank, dev, dist):
         conf["encoder_tflops"] = round(conf["encoder_gflop"] / ms, 2)
         conf["encoder_frac_of_bf16_dense_peak_2500TF"] = round(conf["encoder_gflop"] / ms / 2500.0, 4)
     if rank == 0:
-        print(json.dumps({"metric": name, "value": round(units * args.steps / elapsed, 1), "unit": "tokens/s",
+        print(json.dumps({"metric": name, "value": round(units * args.steps / elapsed, 1), "unit": conf.pop("unit", "tokens/s"),
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": conf}))

@@ -26,15 +26,17 @@ def _device() -> torch.device:
 
 def _pack(seqs: Sequence[Sequence[int]], dev: torch.device, width: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Ragged id lists -> (padded (n, width) int32, lengths (n) int32) on the device."""
+    import numpy as np
     n = len(seqs)
-    ids = torch.zeros((n, max(width, 1)), dtype=torch.int32)
-    lens = torch.empty((n,), dtype=torch.int32)
+    ids = np.zeros((n, max(width, 1)), dtype=np.int32)
+    lens = np.empty((n,), dtype=np.int32)
     for i, s in enumerate(seqs):
-        s = s.tolist() if isinstance(s, torch.Tensor) else list(s)
+        if isinstance(s, torch.Tensor):
+            s = s.tolist()
         lens[i] = len(s)
-        if s:
-            ids[i, : len(s)] = torch.tensor(s, dtype=torch.int32)
-    return ids.to(dev), lens.to(dev)
+        if len(s):
+            ids[i, : len(s)] = s
+    return torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)
 
 
 def sequence_statistics(predictions: Sequence[Sequence[int]], targets: Sequence[Sequence[int]], n: int = 4,
@@ -50,18 +52,22 @@ def sequence_statistics(predictions: Sequence[Sequence[int]], targets: Sequence[
     width = max([len(s) for s in predictions] + [len(s) for s in targets] + [1])
     p_ids, p_len = _pack(predictions, dev, width)
     t_ids, t_len = _pack(targets, dev, width)
-    return device_sequence_statistics(p_ids, p_len, t_ids, t_len, n, pad_token_id)
+    return device_sequence_statistics(p_ids, p_len, t_ids, t_len, n, pad_token_id, _max_len=width)
 
 
 def device_sequence_statistics(p_ids: torch.Tensor, p_len: torch.Tensor, t_ids: torch.Tensor, t_len: torch.Tensor,
-                               n: int = 4, pad_token_id: int = 0) -> Dict[str, torch.Tensor]:
+                               n: int = 4, pad_token_id: int = 0, _max_len: int = None) -> Dict[str, torch.Tensor]:
     """Same for id matrices that already live on the device ((P, W) int32 + lengths), e.g. the decode kernel's output."""
     for name, t in (("pred ids", p_ids), ("pred lengths", p_len), ("target ids", t_ids), ("target lengths", t_len)):
         _lib.require_gpu(t, name, torch.int32)
     pairs = p_ids.shape[0]
-    max_len = int(max(int(p_len.max()), int(t_len.max()), 0))
-    if int(p_len.max()) > p_ids.shape[1] or int(t_len.max()) > t_ids.shape[1]:
-        raise RuntimeError("sequence length exceeds the id matrix width")
+    if _max_len is None:                                             # one sync; the list entry point knows it already
+        pm, tm = int(p_len.max()), int(t_len.max())
+        if pm > p_ids.shape[1] or tm > t_ids.shape[1]:
+            raise RuntimeError("sequence length exceeds the id matrix width")
+        max_len = max(pm, tm, 0)
+    else:
+        max_len = int(_max_len)
     if p_ids.shape[1] < max_len or t_ids.shape[1] < max_len:        # the kernel indexes rows up to max_len
         pad = lambda m: torch.nn.functional.pad(m, (0, max_len - m.shape[1]))
         p_ids, t_ids = pad(p_ids).contiguous(), pad(t_ids).contiguous()
