@@ -512,3 +512,33 @@ def test_grouped_decode_matches_row_per_workgroup_kernel(rows):
             t0 = int(diff[0])
             assert margin[r, t0] < 2e-4, (r, t0, margin[r, t0])
     assert (a == b).mean() > 0.97
+
+
+def test_grouped_decode_under_concurrent_load():
+    """The in-launch exchanges of the grouped kernel must not depend on timing or on having the GPU to itself:
+    (a) decode while another stream keeps the CUs busy with conv launches (the group members start at different
+    times and wait for each other), (b) two grouped decodes on two streams at once (each sees roughly half of the
+    CUs; in-order dispatch keeps complete groups running).  Ids must equal the quiet run, no poll may time out."""
+    d, cfg, sd_kw = load("primary_cfg2_clock")
+    m, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    m2, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(DEV)
+    T = 150
+    with torch.no_grad():
+        enc = m.encoder(x)
+        quiet, _ = m.greedy_ids(enc, START, END, T)
+        quiet = _lib.check_ids(quiet.cpu())
+        side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+        for rep in range(3):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):                   # (a) encoder traffic next to the decode
+                for _ in range(4):
+                    m2.encoder(x)
+            busy, _ = m.greedy_ids(enc, START, END, T)
+            with torch.cuda.stream(side):                   # (b) a second grouped decode (own model = own workspace)
+                other, _ = m2.greedy_ids(enc, START, END, T)
+            again, _ = m.greedy_ids(enc, START, END, T)
+            main.wait_stream(side)
+            torch.cuda.synchronize()
+            for got in (busy, other, again):
+                assert torch.equal(_lib.check_ids(got.cpu()), quiet), rep
