@@ -1,0 +1,74 @@
+// Helpers shared by the grouped persistent kernels (decode_group.inc.h, train_group.inc.h): tagged-granule
+// exchange between the workgroups of a group, DPP reduce-scatter, packed-FMA tiles, arg-max keys.
+// Included inside each translation unit's anonymous namespace.
+#pragma once
+typedef unsigned long long u64_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr long long GRP_TIMEOUT_TICKS = 300000000ll;   // 3 s of the 100 MHz wall clock
+
+
+// local == false: sc1 store (write-through to memory, seen from every XCD).  local == true (all four members were
+// found on ONE XCD): sc0 store, the line stays in that XCD's L2 where the peers' sc1 loads (L1 bypassed) find it --
+// an L2 round trip instead of a memory one.
+__device__ __forceinline__ void store_granule(u64_t* g, u64_t v, bool local) {
+    if (local) __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64_t granule(unsigned tag, float v) { return ((u64_t)tag << 32) | (u64_t)__float_as_uint(v); }
+__device__ __forceinline__ u64_t load_granule(const u64_t* g) {
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// DPP controls: quad_perm [1,0,3,2] (lane ^ 1), quad_perm [2,3,0,1] (lane ^ 2), row_half_mirror (lane -> 7 - lane
+// within 8), row_ror:n (rotate within 16), row_shl:n (lane reads lane + n)
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HMIRROR = 0x141, DPP_ROR4 = 0x124, DPP_ROR8 = 0x128,
+              DPP_SHL4 = 0x104, DPP_SHL8 = 0x108;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// One level of a reduce-scatter between a lane and its DPP partner: the pair holds partial sums of the same two
+// values (a, b); the lane with sel == false keeps a, its partner keeps b, each adds the other's partial.
+template <int CTRL>
+__device__ __forceinline__ float rs_level(float a, float b, bool sel) {
+    const float keep = sel ? b : a, send = sel ? a : b;
+    return keep + dpp_f<CTRL>(send);
+}
+__device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
+// (value, index) as one unsigned 64-bit key whose order is "larger value first, then smaller index": arg max with
+// first-index ties becomes a branch-free integer max
+__device__ __forceinline__ u64_t am_key(float v, int i) {
+    unsigned u = __float_as_uint(v + 0.0f);                 // -0 -> +0
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((u64_t)u << 32) | (u64_t)(0xFFFFFFFFu - (unsigned)i);
+}
+__device__ __forceinline__ float am_val(u64_t k) {
+    unsigned u = (unsigned)(k >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int am_idx(u64_t k) { return (int)(0xFFFFFFFFu - (unsigned)k); }
+__device__ __forceinline__ u64_t umax64(u64_t a, u64_t b) { return a > b ? a : b; }
+template <int CTRL>
+__device__ __forceinline__ u64_t dpp_u64(u64_t k) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)k, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(k >> 32), CTRL, 0xF, 0xF, true);
+    return ((u64_t)hi << 32) | lo;
+}
+// acc(2 rows) += w.x * h(2 rows) / w.y * h: v_pk_fma_f32 with the scalar picked by op_sel, so a weight PAIR
+// occupies one register pair (the compiler's own splat {w, w} would double the resident weights)
+__device__ __forceinline__ void pkfma_lo(f32x2& acc, f32x2 wpair, f32x2 h) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(wpair), "v"(h));
+}
+__device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 wpair, f32x2 h) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(wpair), "v"(h));
+}
+// acc[4 values][2 row pairs] += w4 (4 values: gates or columns) x h4 (4 rows)
+__device__ __forceinline__ void fma_4x4(f32x2 (&acc)[4][2], f32x2 w01, f32x2 w23, float4 hv) {
+    const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+    pkfma_lo(acc[0][0], w01, h01); pkfma_lo(acc[0][1], w01, h23);
+    pkfma_hi(acc[1][0], w01, h01); pkfma_hi(acc[1][1], w01, h23);
+    pkfma_lo(acc[2][0], w23, h01); pkfma_lo(acc[2][1], w23, h23);
+    pkfma_hi(acc[3][0], w23, h01); pkfma_hi(acc[3][1], w23, h23);
+}
+

@@ -17,6 +17,7 @@
 // source the context equals enc (see decode.hip), and the attention parameters receive an
 // exactly-zero gradient: the host zero-fills them.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -158,6 +159,8 @@ __device__ __forceinline__ void matvec_res(float4& acc, const float4 (&wres)[KR 
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+#include "train_group.inc.h"
 
 // ------------------------------------------------------------------ saved tensors
 struct TrainBuf {
@@ -525,8 +528,9 @@ __global__ void bias_gate_kernel(const float* __restrict__ b_ih, const float* __
 // ------------------------------------------------------------------ workspace layout
 struct TLayout {
     size_t X, GX, WhhT[MAXL], WihT[MAXL], biasP[MAXL], ACT[MAXL], C[MAXL], Hout[MAXL], Hprev[MAXL], Hdrop, DG[MAXL],
-        dHdrop, dX, row_loss, row_keep, colpart, gemm_ws, total;
-    size_t gemm_ws_bytes;
+        dHdrop, dX, row_loss, row_keep, colpart, gemm_ws, xchg, total;
+    size_t gemm_ws_bytes, xchg_bytes;
+    int n_groups;
 };
 
 TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
@@ -560,8 +564,19 @@ TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
     o.gemm_ws = off;
     o.gemm_ws_bytes = i2l_align(g);
     off += o.gemm_ws_bytes;
+    if (L == 1 && H == 256) {           // grouped recurrences (train_group.inc.h): status block + exchange granules
+        o.n_groups = i2l_cdiv(B, 4);
+        o.xchg = off;
+        o.xchg_bytes = 2048 + (size_t)i2l_cdiv(o.n_groups, 8) * 8 * 2 * 4 * TGB_GRAN * sizeof(u64_t);
+        off += i2l_align(o.xchg_bytes);
+    }
     o.total = off;
     return o;
+}
+
+bool train_group_enabled() {
+    static const bool off = getenv("I2L_TRAIN_GROUP") != nullptr && atoi(getenv("I2L_TRAIN_GROUP")) == 0;
+    return !off;
 }
 
 int check_w(const i2l_decoder_weights* w) {
@@ -656,7 +671,18 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
         if (lds > 64 * 1024) return I2L_ERR_UNSUPPORTED;
         dim3 grid(i2l_cdiv(B, R));
         bool done = false;
-        if (R == 1 && L == 1 && H == NT && T >= 8) {        // part of W_hh resident on chip
+        if (lo.xchg_bytes && T >= 8 && train_group_enabled()) {  // 4 workgroups share 4 rows, W_hh in registers
+            TrainGroupFwd gp{};
+            gp.B = B; gp.T = T; gp.n_groups = lo.n_groups; gp.GX = p.GX; gp.WhhT = p.WhhT[0];
+            gp.ACT = p.ACT[0]; gp.C = p.C[0]; gp.Hout = p.Hout[0]; gp.Hprev = p.Hprev[0];
+            gp.status = reinterpret_cast<unsigned*>(base + lo.xchg);
+            gp.xchg = reinterpret_cast<u64_t*>(base + lo.xchg + 2048);
+            const size_t used = 2048 + (size_t)i2l_cdiv(lo.n_groups, 8) * 8 * 2 * 4 * TGF_GRAN * sizeof(u64_t);
+            if (hipMemsetAsync(base + lo.xchg, 0, used, s) != hipSuccess) return I2L_ERR_LAUNCH;
+            hipLaunchKernelGGL(lstm_train_fwd_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);
+            done = true;
+        }
+        if (!done && R == 1 && L == 1 && H == NT && T >= 8) {        // part of W_hh resident on chip
             const size_t lds_r = lds + (size_t)RES_KL * G * sizeof(float);
             auto kern = lstm_train_fwd_kernel<1, RES_KR, RES_KL>;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -769,7 +795,17 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         if (lds > 64 * 1024) return I2L_ERR_UNSUPPORTED;
         dim3 grid(i2l_cdiv(B, R));
         bool done = false;
-        if (R == 1 && L == 1 && H == NT && T >= 8) {
+        if (lo.xchg_bytes && T >= 8 && train_group_enabled()) {
+            TrainGroupBwd gp{};
+            gp.B = B; gp.T = T; gp.n_groups = lo.n_groups; gp.ACT = p.ACT[0]; gp.C = p.C[0]; gp.dHtop = p.dHtop;
+            gp.Whh = p.Whh[0]; gp.DG = p.DG[0];
+            gp.status = reinterpret_cast<unsigned*>(base + lo.xchg);
+            gp.xchg = reinterpret_cast<u64_t*>(base + lo.xchg + 2048);
+            if (hipMemsetAsync(base + lo.xchg, 0, lo.xchg_bytes, s) != hipSuccess) return I2L_ERR_LAUNCH;
+            hipLaunchKernelGGL(lstm_train_bwd_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);
+            done = true;
+        }
+        if (!done && R == 1 && L == 1 && H == NT && T >= 8) {
             const size_t lds_r = lds + (size_t)NG * RES_KL * H * sizeof(float);
             auto kern = lstm_train_bwd_kernel<1, RES_KR, RES_KL>;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
