@@ -30,14 +30,15 @@ def build(name):
     return d, cfg, m.to(DEV)
 
 
-@pytest.mark.parametrize("name", SMALL + ["primary"])
-def test_decoder_backward_vs_oracle(name):
-    """d(loss)/d(decoder params) and d(loss)/d(enc) for the teacher-forced decoder, dropout 0."""
+@pytest.mark.parametrize("name,batch", [(n, 4) for n in SMALL + ["primary"]] + [("primary", 7), ("primary", 1)])
+def test_decoder_backward_vs_oracle(name, batch):
+    """d(loss)/d(decoder params) and d(loss)/d(enc) for the teacher-forced decoder, dropout 0.  The primary config
+    runs the grouped recurrences (4 workgroups per 4 rows): batch 7 and 1 leave a group with missing rows."""
     d, cfg, m = build(name)
     sd = torch_state_dict(name)
     T = 12
-    forms = torch.from_numpy(synth.make_formulas(4, T, cfg["vocab_size"], seed=777, min_len=5))
-    x = images(cfg)
+    forms = torch.from_numpy(synth.make_formulas(batch, T, cfg["vocab_size"], seed=777, min_len=5))
+    x = images(cfg) if batch == 4 else torch.from_numpy(synth.make_images(batch, cfg, seed=99))
     with torch.no_grad():
         enc_cpu = O.cnn_encoder(sd, cfg, x)
     # oracle: autograd through the restated decoder + CE
