@@ -30,6 +30,7 @@ struct GemmArgs {
     int perm_h;
     float alpha;
     int accumulate;           // C += result instead of C = result
+    int split_bf16;           // allow the split-bf16 matrix-core kernel (fp32-grade, not an fmaf chain); gemm.hip
 };
 static inline GemmArgs gemm_args() {
     GemmArgs g{};

@@ -237,50 +237,71 @@ __device__ __forceinline__ void lsplit_piece(const float4& lo, const float4& hi,
     for (int sp = 0; sp < 3; ++sp) out[sp] = make_uint4(p[sp][0], p[sp][1], p[sp][2], p[sp][3]);
 }
 
-__global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(GemmArgs g, float* __restrict__ partial, int k_chunk,
-                                                               int S, int tiles_n, int tiles) {
+template <bool A_KC, bool W_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* __restrict__ partial, int k_chunk,
+                                                             int S, int tiles_n, int tiles) {
     __shared__ __attribute__((aligned(16))) uint4 a_s[3 * 4 * LPA];
     __shared__ __attribute__((aligned(16))) uint4 w_s[3 * 4 * LPW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;
-    const int L = blockIdx.x, grp = L >> 3;
-    const int tile = grp % tiles, slice = (L & 7) + 8 * (grp / tiles);
+    // K slices a multiple of 8: workgroups that share a slice (same operand bytes) get block ids equal mod 8 = one XCD
+    // under round-robin placement (speed only); otherwise the plain order (every XCD gets work)
+    const int L = blockIdx.x;
+    int tile, slice;
+    if ((S & 7) == 0) { const int grp = L >> 3; tile = grp % tiles; slice = (L & 7) + 8 * (grp / tiles); }
+    else { tile = L % tiles; slice = L / tiles; }
     if (slice >= S) return;
     const int m0 = (tile / tiles_n) * LBM, n0 = (tile % tiles_n) * LBN;
     const int kbeg = slice * k_chunk, kend = min(g.K, kbeg + k_chunk);
 
-    // staging: piece = (row, k group kg of 8); A: 2 pieces per thread, W: 1
-    const int srow = tid >> 2, skg = tid & 3;
-    const float* pa0 = g.A + (size_t)min(m0 + srow, g.M - 1) * g.lda + skg * 8;
-    const float* pa1 = g.A + (size_t)min(m0 + 64 + srow, g.M - 1) * g.lda + skg * 8;
-    const float* pw = g.W + (size_t)min(n0 + srow, g.N - 1) * g.ldw + skg * 8;
-    const bool oka0 = m0 + srow < g.M, oka1 = m0 + 64 + srow < g.M, okw = n0 + srow < g.N;
+    // staging: piece = (row, k group kg of 8); A: 2 pieces per thread, W: 1.  K-contiguous operands: 4 lanes cover the
+    // 4 k groups of one row (two float4 loads each); M/N-contiguous operands: consecutive lanes = consecutive rows
+    // (8 strided 4-byte loads each, coalesced across lanes).  Either way a piece lands at (split, kg) plane + row.
+    const int a_row0 = A_KC ? (tid >> 2) : (tid & 127), a_kg0 = A_KC ? (tid & 3) : (tid >> 7);
+    const int a_row1 = A_KC ? 64 + (tid >> 2) : (tid & 127), a_kg1 = A_KC ? (tid & 3) : 2 + (tid >> 7);
+    const int w_row = W_KC ? (tid >> 2) : (tid & 63), w_kg = W_KC ? (tid & 3) : (tid >> 6);
+    const bool oka0 = m0 + a_row0 < g.M, oka1 = m0 + a_row1 < g.M, okw = n0 + w_row < g.N;
+    const float* pa0 = A_KC ? g.A + (size_t)min(m0 + a_row0, g.M - 1) * g.lda : g.A + min(m0 + a_row0, g.M - 1);
+    const float* pa1 = A_KC ? g.A + (size_t)min(m0 + a_row1, g.M - 1) * g.lda : g.A + min(m0 + a_row1, g.M - 1);
+    const float* pw = W_KC ? g.W + (size_t)min(n0 + w_row, g.N - 1) * g.ldw : g.W + min(n0 + w_row, g.N - 1);
     // three register stages: the loads of chunk c+2 are issued while chunk c computes (one chunk of MFMAs is only
     // ~0.4 us, shorter than a memory round trip)
     struct Stage { float4 a[2][2], w[2]; };
     Stage st0, st1, st2;
-    auto fetch = [&](Stage& st, int k0) {
-        const bool okk = k0 + skg * 8 < kend;               // K % 8 == 0: a piece is inside or outside as a whole
+    auto load8 = [&](bool kc, const float* base, long ld, bool ok, int k, float4& lo, float4& hi) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        st.a[0][0] = (oka0 && okk) ? *reinterpret_cast<const float4*>(pa0 + k0) : z;
-        st.a[0][1] = (oka0 && okk) ? *reinterpret_cast<const float4*>(pa0 + k0 + 4) : z;
-        st.a[1][0] = (oka1 && okk) ? *reinterpret_cast<const float4*>(pa1 + k0) : z;
-        st.a[1][1] = (oka1 && okk) ? *reinterpret_cast<const float4*>(pa1 + k0 + 4) : z;
-        st.w[0] = (okw && okk) ? *reinterpret_cast<const float4*>(pw + k0) : z;
-        st.w[1] = (okw && okk) ? *reinterpret_cast<const float4*>(pw + k0 + 4) : z;
+        lo = z; hi = z;
+        if (!ok) return;
+        if (kc) {                                            // K % 8 == 0: a piece is inside or outside as a whole
+            if (k < kend) {
+                lo = *reinterpret_cast<const float4*>(base + k);
+                hi = *reinterpret_cast<const float4*>(base + k + 4);
+            }
+        } else {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = k + j < kend ? base[(size_t)(k + j) * ld] : 0.f;
+            lo = make_float4(v[0], v[1], v[2], v[3]);
+            hi = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    };
+    auto fetch = [&](Stage& st, int k0) {
+        load8(A_KC, pa0, g.lda, oka0, k0 + a_kg0 * 8, st.a[0][0], st.a[0][1]);
+        load8(A_KC, pa1, g.lda, oka1, k0 + a_kg1 * 8, st.a[1][0], st.a[1][1]);
+        load8(W_KC, pw, g.ldw, okw, k0 + w_kg * 8, st.w[0], st.w[1]);
     };
     auto commit = [&](const Stage& st) {
         uint4 o[3];
         lsplit_piece(st.a[0][0], st.a[0][1], o);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + skg) * LPA + srow] = o[sp];
+        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + a_kg0) * LPA + a_row0] = o[sp];
         lsplit_piece(st.a[1][0], st.a[1][1], o);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + skg) * LPA + 64 + srow] = o[sp];
+        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + a_kg1) * LPA + a_row1] = o[sp];
         lsplit_piece(st.w[0], st.w[1], o);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) w_s[(sp * 4 + skg) * LPW + srow] = o[sp];
+        for (int sp = 0; sp < 3; ++sp) w_s[(sp * 4 + w_kg) * LPW + w_row] = o[sp];
     };
 
     f32x16 acc[2];
@@ -347,11 +368,42 @@ void plan_bf16x3(int M, int N, int K, int* S, int* k_chunk) {
     *k_chunk = kc;
 }
 
-bool linear_bf16x3_applicable(const float* x, const float* w, int M, int K, int N) {
+bool split_bf16_exact_mode() {
     static const bool exact = getenv("I2L_CONV_EXACT_FP32") != nullptr && atoi(getenv("I2L_CONV_EXACT_FP32")) != 0;
-    (void)M; (void)N;
-    return !exact && K >= 2048 && K % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
-           reinterpret_cast<uintptr_t>(w) % 16 == 0;
+    return exact;
+}
+
+// can this GEMM run on gemm_bf16x3_kernel?  (single operand pair, K-contiguous operands 16-byte aligned with K % 8 == 0)
+bool bf16x3_applicable(const GemmArgs& g) {
+    if (split_bf16_exact_mode() || g.nz > 1 || g.K < 64) return false;
+    auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (g.a_kc && (!al16(g.A) || g.lda % 4 != 0 || g.K % 8 != 0)) return false;
+    if (g.w_kc && (!al16(g.W) || g.ldw % 4 != 0 || g.K % 8 != 0)) return false;
+    return true;
+}
+
+int run_bf16x3(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s) {
+    int S, kc;
+    plan_bf16x3(g.M, g.N, g.K, &S, &kc);
+    if (S > 1 && (!ws || ws_bytes < (size_t)S * slab_stride(g.M, g.N) * sizeof(float))) return I2L_ERR_WORKSPACE;
+    const int tiles_n = i2l_cdiv(g.N, LBN), tiles = i2l_cdiv(g.M, LBM) * tiles_n;
+    const long long blocks = (long long)tiles * S;
+    if (blocks > 0x7fffffffll) return I2L_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)blocks);
+    float* wsf = static_cast<float*>(ws);
+    if (g.a_kc && g.w_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
+    else if (g.a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
+    else if (g.w_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
+    I2L_CHECK_LAUNCH();
+    if (S > 1) {
+        const size_t total = (size_t)g.M * g.N;
+        int rb = (int)((total + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, g, (const float*)ws, S);
+        I2L_CHECK_LAUNCH();
+    }
+    return I2L_OK;
 }
 
 }  // namespace
@@ -360,13 +412,21 @@ size_t i2l_gemm_workspace_bytes(int M, int N, int K, int nz) {
     int ks, kc;
     plan(M, N, K, nz < 1 ? 1 : nz, &ks, &kc);
     const size_t slabs = (size_t)ks * (nz < 1 ? 1 : nz);
-    return slabs > 1 ? i2l_align(slabs * slab_stride(M, N) * sizeof(float)) : 0;
+    size_t need = slabs > 1 ? i2l_align(slabs * slab_stride(M, N) * sizeof(float)) : 0;
+    if (nz <= 1 && K >= 64) {                  // the split-bf16 kernel's slabs (GemmArgs::split_bf16)
+        int S, kc;
+        plan_bf16x3(M, N, K, &S, &kc);
+        const size_t n3 = S > 1 ? i2l_align((size_t)S * slab_stride(M, N) * sizeof(float)) : 0;
+        if (n3 > need) need = n3;
+    }
+    return need;
 }
 
 int i2l_gemm(const GemmArgs& g0, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmArgs g = g0;
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return I2L_ERR_ARG;
     if (g.nz < 1) g.nz = 1;
+    if (g.split_bf16 && bf16x3_applicable(g)) return run_bf16x3(g, ws, ws_bytes, stream);
     int ks, kc;
     plan(g.M, g.N, g.K, g.nz, &ks, &kc);
     const int slabs = ks * g.nz;
@@ -394,14 +454,7 @@ int i2l_gemm(const GemmArgs& g0, void* ws, size_t ws_bytes, hipStream_t stream) 
 
 extern "C" size_t i2l_linear_workspace_bytes(int M, int K, int N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    size_t need = i2l_gemm_workspace_bytes(M, N, K, 1);
-    if (K >= 2048 && K % 8 == 0) {            // the split-bf16 path's slabs (linear_bf16x3_kernel)
-        int S, kc;
-        plan_bf16x3(M, N, K, &S, &kc);
-        const size_t n3 = S > 1 ? i2l_align((size_t)S * slab_stride(M, N) * sizeof(float)) : 0;
-        if (n3 > need) need = n3;
-    }
-    return need;
+    return i2l_gemm_workspace_bytes(M, N, K, 1);
 }
 
 extern "C" int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -415,24 +468,7 @@ extern "C" int i2l_linear_bias_act_fwd(const float* x, const float* w, const flo
     g.C = y; g.ldc = N;
     g.M = M; g.N = N; g.K = K;
     g.relu = relu ? 1 : 0;
-    if (linear_bf16x3_applicable(x, w, M, K, N)) {
-        int S, kc;
-        plan_bf16x3(M, N, K, &S, &kc);
-        if (S > 1 && (!workspace || workspace_bytes < (size_t)S * slab_stride(M, N) * sizeof(float))) return I2L_ERR_WORKSPACE;
-        const int tiles_n = i2l_cdiv(N, LBN), tiles = i2l_cdiv(M, LBM) * tiles_n;
-        hipStream_t s = i2l_s(stream);
-        hipLaunchKernelGGL(linear_bf16x3_kernel, dim3(8 * tiles * i2l_cdiv(S, 8)), dim3(256), 0, s, g,
-                           static_cast<float*>(workspace), kc, S, tiles_n, tiles);
-        I2L_CHECK_LAUNCH();
-        if (S > 1) {
-            const size_t total = (size_t)M * N;
-            int blocks = (int)((total + 255) / 256);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, (const float*)workspace, S);
-            I2L_CHECK_LAUNCH();
-        }
-        return I2L_OK;
-    }
+    g.split_bf16 = K >= 2048;                  // long reductions (the encoder FC): bf16 matrix cores, fp32-grade result
     return i2l_gemm(g, workspace, workspace_bytes, i2l_s(stream));
 }
 
@@ -484,6 +520,7 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
     I2L_CHECK_LAUNCH();
     {   // dw[n][k] = sum_m d[m][n] * x[m][k]
         GemmArgs g = gemm_args();
+        g.split_bf16 = 1;
         g.A = d; g.lda = N; g.a_kc = 0;
         g.W = x; g.ldw = K; g.w_kc = 0;
         g.C = dw; g.ldc = K;
@@ -493,6 +530,7 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
     }
     if (dx) {   // dx[m][k] = sum_n d[m][n] * w[n][k]
         GemmArgs g = gemm_args();
+        g.split_bf16 = 1;
         g.A = d; g.lda = N;
         g.W = w; g.ldw = K; g.w_kc = 0;
         g.C = dx; g.ldc = K;

@@ -638,6 +638,7 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
     I2L_CHECK_LAUNCH();
     {   // GX = X @ W_ih_0^T + b_ih_0 + b_hh_0, gate-interleaved
         GemmArgs g = gemm_args();
+            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = F(lo.X); g.lda = 2 * E;
         g.W = w->w_ih[0]; g.ldw = 2 * E;
         g.bias = w->b_ih[0]; g.bias2 = w->b_hh[0];
@@ -703,6 +704,7 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
     I2L_CHECK_LAUNCH();
     {   // logits = Hdrop @ W_out^T + b_out
         GemmArgs g = gemm_args();
+            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = F(lo.Hdrop); g.lda = H;
         g.W = w->w_out; g.ldw = H;
         g.bias = w->b_out;
@@ -756,6 +758,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
 
     {   // dW_out[v][h] = sum_bt dlogits[bt][v] * Hdrop[bt][h]
         GemmArgs g = gemm_args();
+            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = dlogits; g.lda = V; g.a_kc = 0;
         g.W = F(lo.Hdrop); g.ldw = H; g.w_kc = 0;
         g.C = gr->w_out; g.ldc = H;
@@ -767,6 +770,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     if (rc != I2L_OK) return rc;
     {   // dHdrop[bt][h] = sum_v dlogits[bt][v] * W_out[v][h]
         GemmArgs g = gemm_args();
+            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = dlogits; g.lda = V;
         g.W = w->w_out; g.ldw = H; g.w_kc = 0;
         g.C = F(lo.dHdrop); g.ldc = H;
@@ -826,6 +830,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         const float* DGl = F(lo.DG[l]);
         {   // dW_ih_l[n][k] = sum_bt DG[bt][n] * In[bt][k]
             GemmArgs g = gemm_args();
+            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
             g.A = DGl; g.lda = G; g.a_kc = 0;
             if (l == 0) { g.W = F(lo.X); g.ldw = 2 * E; g.N = 2 * E; }
             else { g.W = F(lo.Hdrop); g.ldw = H; g.N = H; }     // placeholder, replaced below for l > 0
@@ -845,6 +850,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         }
         {   // dW_hh_l[n][k] = sum_bt DG[bt][n] * h_{t-1}[bt][k]
             GemmArgs g = gemm_args();
+            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
             g.A = DGl; g.lda = G; g.a_kc = 0;
             g.W = F(lo.Hprev[l]); g.ldw = H; g.w_kc = 0;
             g.C = gr->w_hh[l]; g.ldc = H;
@@ -857,6 +863,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     }
     {   // dX[bt][k] = sum_n DG0[bt][n] * W_ih_0[n][k]
         GemmArgs g = gemm_args();
+            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = F(lo.DG[0]); g.lda = G;
         g.W = w->w_ih[0]; g.ldw = 2 * E; g.w_kc = 0;
         g.C = F(lo.dX); g.ldc = 2 * E;
