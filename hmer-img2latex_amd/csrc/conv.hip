@@ -600,6 +600,7 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         g.A = dyp + (size_t)b0 * Cout * HW; g.lda = (long)HW; g.bsa = (long)(Cout * HW);
         g.W = colT; g.ldw = (long)HW; g.bsw = (long)(Cin * 9 * HW);
         g.nz = nb;
+        g.split_bf16 = 1;      // training GEMM: 3-way split bf16 matrix cores where the shape allows (gemm.hip)
         g.C = dw; g.ldc = Cin * 9;
         g.M = Cout; g.N = Cin * 9; g.K = (int)HW;
         g.accumulate = b0 > 0 ? 1 : 0;

@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
     else { tile = L % tiles; slice = L / tiles; }
     if (slice >= S) return;
     const int m0 = (tile / tiles_n) * LBM, n0 = (tile % tiles_n) * LBN;
-    const int kbeg = slice * k_chunk, kend = min(g.K, kbeg + k_chunk);
+    // the reduction runs over the flattened (operand pair z, k) range; K % 32 == 0 when nz > 1, so a chunk never
+    // straddles two pairs
+    const long kf_beg = (long)slice * k_chunk, kf_end = min((long)g.nz * g.K, kf_beg + k_chunk);
 
     // staging: piece = (row, k group kg of 8); A: 2 pieces per thread, W: 1.  K-contiguous operands: 4 lanes cover the
     // 4 k groups of one row (two float4 loads each); M/N-contiguous operands: consecutive lanes = consecutive rows
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
     // ~0.4 us, shorter than a memory round trip)
     struct Stage { float4 a[2][2], w[2]; };
     Stage st0, st1, st2;
-    auto load8 = [&](bool kc, const float* base, long ld, bool ok, int k, float4& lo, float4& hi) {
+    auto load8 = [&](bool kc, const float* base, long ld, bool ok, int k, int kend, float4& lo, float4& hi) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         lo = z; hi = z;
         if (!ok) return;
@@ -286,10 +288,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
             hi = make_float4(v[4], v[5], v[6], v[7]);
         }
     };
-    auto fetch = [&](Stage& st, int k0) {
-        load8(A_KC, pa0, g.lda, oka0, k0 + a_kg0 * 8, st.a[0][0], st.a[0][1]);
-        load8(A_KC, pa1, g.lda, oka1, k0 + a_kg1 * 8, st.a[1][0], st.a[1][1]);
-        load8(W_KC, pw, g.ldw, okw, k0 + w_kg * 8, st.w[0], st.w[1]);
+    auto fetch = [&](Stage& st, long kf0) {
+        const int z = (int)(kf0 / g.K), k0 = (int)(kf0 - (long)z * g.K);
+        const int kend = (int)min((long)g.K, kf_end - (long)z * g.K);
+        const size_t oa = (size_t)z * g.bsa, ow = (size_t)z * g.bsw;
+        load8(A_KC, pa0 + oa, g.lda, oka0, k0 + a_kg0 * 8, kend, st.a[0][0], st.a[0][1]);
+        load8(A_KC, pa1 + oa, g.lda, oka1, k0 + a_kg1 * 8, kend, st.a[1][0], st.a[1][1]);
+        load8(W_KC, pw + ow, g.ldw, okw, k0 + w_kg * 8, kend, st.w[0], st.w[1]);
     };
     auto commit = [&](const Stage& st) {
         uint4 o[3];
@@ -310,10 +315,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    auto step = [&](const Stage& cur, Stage& nxt2, int k0) {
+    auto step = [&](const Stage& cur, Stage& nxt2, long k0) {
         commit(cur);
         __syncthreads();
-        if (k0 + 2 * LBK < kend) fetch(nxt2, k0 + 2 * LBK);
+        if (k0 + 2 * LBK < kf_end) fetch(nxt2, k0 + 2 * LBK);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8_t a[2][3], b[3];
@@ -337,12 +342,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         }
         __syncthreads();
     };
-    fetch(st0, kbeg);
-    if (kbeg + LBK < kend) fetch(st1, kbeg + LBK);
-    for (int k0 = kbeg; k0 < kend; k0 += 3 * LBK) {
+    fetch(st0, kf_beg);
+    if (kf_beg + LBK < kf_end) fetch(st1, kf_beg + LBK);
+    for (long k0 = kf_beg; k0 < kf_end; k0 += 3 * LBK) {
         step(st0, st2, k0);
-        if (k0 + LBK < kend) step(st1, st0, k0 + LBK);
-        if (k0 + 2 * LBK < kend) step(st2, st1, k0 + 2 * LBK);
+        if (k0 + LBK < kf_end) step(st1, st0, k0 + LBK);
+        if (k0 + 2 * LBK < kf_end) step(st2, st1, k0 + 2 * LBK);
     }
     const int n = n0 + wn * 32 + i;
 #pragma unroll
@@ -357,15 +362,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         }
 }
 
-void plan_bf16x3(int M, int N, int K, int* S, int* k_chunk) {
+void plan_bf16x3(int M, int N, long KT, int* S, int* k_chunk) {      // KT = nz * K, the flattened reduction length
     const int tiles = i2l_cdiv(M, LBM) * i2l_cdiv(N, LBN);
-    int s = 512 / tiles;
-    const int max_s = K / 256;                // keep >= 256 of K per slice
+    long s = 512 / tiles;
+    const long max_s = KT / 256;              // keep >= 256 of the reduction per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    int kc = i2l_cdiv(i2l_cdiv(K, s), LBK) * LBK;
-    *S = i2l_cdiv(K, kc);
-    *k_chunk = kc;
+    const long kc = ((KT + s - 1) / s + LBK - 1) / LBK * LBK;
+    *S = (int)((KT + kc - 1) / kc);
+    *k_chunk = (int)kc;
 }
 
 bool split_bf16_exact_mode() {
@@ -375,7 +380,7 @@ bool split_bf16_exact_mode() {
 
 // can this GEMM run on gemm_bf16x3_kernel?  (single operand pair, K-contiguous operands 16-byte aligned with K % 8 == 0)
 bool bf16x3_applicable(const GemmArgs& g) {
-    if (split_bf16_exact_mode() || g.nz > 1 || g.K < 64) return false;
+    if (split_bf16_exact_mode() || g.K < 64 || (g.nz > 1 && (g.K % LBK != 0 || (long)g.nz * g.K > 0x7fffffffl))) return false;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     if (g.a_kc && (!al16(g.A) || g.lda % 4 != 0 || g.K % 8 != 0)) return false;
     if (g.w_kc && (!al16(g.W) || g.ldw % 4 != 0 || g.K % 8 != 0)) return false;
@@ -384,7 +389,7 @@ bool bf16x3_applicable(const GemmArgs& g) {
 
 int run_bf16x3(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s) {
     int S, kc;
-    plan_bf16x3(g.M, g.N, g.K, &S, &kc);
+    plan_bf16x3(g.M, g.N, (long)g.nz * g.K, &S, &kc);
     if (S > 1 && (!ws || ws_bytes < (size_t)S * slab_stride(g.M, g.N) * sizeof(float))) return I2L_ERR_WORKSPACE;
     const int tiles_n = i2l_cdiv(g.N, LBN), tiles = i2l_cdiv(g.M, LBM) * tiles_n;
     const long long blocks = (long long)tiles * S;
@@ -413,9 +418,9 @@ size_t i2l_gemm_workspace_bytes(int M, int N, int K, int nz) {
     plan(M, N, K, nz < 1 ? 1 : nz, &ks, &kc);
     const size_t slabs = (size_t)ks * (nz < 1 ? 1 : nz);
     size_t need = slabs > 1 ? i2l_align(slabs * slab_stride(M, N) * sizeof(float)) : 0;
-    if (nz <= 1 && K >= 64) {                  // the split-bf16 kernel's slabs (GemmArgs::split_bf16)
+    if (K >= 64) {                             // the split-bf16 kernel's slabs (GemmArgs::split_bf16)
         int S, kc;
-        plan_bf16x3(M, N, K, &S, &kc);
+        plan_bf16x3(M, N, (long)(nz < 1 ? 1 : nz) * K, &S, &kc);
         const size_t n3 = S > 1 ? i2l_align((size_t)S * slab_stride(M, N) * sizeof(float)) : 0;
         if (n3 > need) need = n3;
     }
