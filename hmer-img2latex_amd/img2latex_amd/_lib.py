@@ -123,6 +123,13 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"img2latex_amd: {what} failed: {lib().i2l_error_string(rc).decode()} (code {rc})")
 
 
+def ids_timed_out(ids_host: torch.Tensor) -> bool:
+    """True when the grouped decode kernel gave up on one of its bounded inter-workgroup waits: it then fills the
+    whole id row with -3 (decode_group.inc.h), so the first column tells (a pinned buffer is slow to scan)."""
+    first = ids_host[:, 0] if ids_host.dim() == 2 else ids_host
+    return bool(first.numel()) and bool((first == -3).any())
+
+
 def check_ids(ids_host: torch.Tensor) -> torch.Tensor:
     """The grouped decode kernel marks every id of a row with -3 when one of its bounded inter-workgroup
     polls expired (decode_group.inc.h); surface that as an error instead of returning garbage."""

@@ -8,6 +8,7 @@ device->host copy of the ids at the end instead of a sync per step).
 from __future__ import annotations
 
 import ctypes
+import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -87,7 +88,15 @@ class Seq2SeqModel(nn.Module):
         rows independently, so that step is located in the ids afterwards."""
         B = encoder_output.shape[0]
         ids, _ = self.greedy_ids(encoder_output, start_token_id, end_token_id, max_length, temperature)
-        ids = _lib.check_ids(ids.cpu())                           # the ONE device->host sync of the search
+        ids = ids.cpu()                                           # the ONE device->host sync of the search
+        if _lib.ids_timed_out(ids):
+            # the grouped kernel needs its 4 members resident together; on a GPU shared with other work (fewer than
+            # 32 free CUs) a bounded wait can expire -> run the row-per-workgroup HIP kernel, which needs no partner
+            warnings.warn("img2latex_amd: grouped decode timed out (GPU oversubscribed?); "
+                          "re-running on the row-per-workgroup kernel", RuntimeWarning)
+            ids, _ = self.greedy_ids(encoder_output, start_token_id, end_token_id, max_length, temperature,
+                                     rows_per_workgroup=1)
+            ids = _lib.check_ids(ids.cpu())
         all_end = (ids == end_token_id).all(dim=0)
         steps = int(all_end.nonzero()[0]) + 1 if bool(all_end.any()) else max_length
         rows = ids[:, :steps].tolist()
