@@ -75,7 +75,11 @@ class Seq2SeqModel(nn.Module):
                    want_logits: bool = False, rows_per_workgroup: int = 0):
         """Device-side greedy loop; returns (ids (B,T) int32 on device, logits or None)."""
         B = encoder_output.shape[0]
-        tok0 = torch.full((B,), int(start_token_id), dtype=torch.int32, device=encoder_output.device)
+        key = (B, int(start_token_id), encoder_output.device)
+        if getattr(self, "_tok0_key", None) != key:               # the START column: built once per batch shape
+            self._tok0 = torch.full((B,), int(start_token_id), dtype=torch.int32, device=encoder_output.device)
+            self._tok0_key = key
+        tok0 = self._tok0
         ids, logits, _ = self.decoder.run_steps(encoder_output, max_length, tok0, temperature=temperature,
                                                 select=select, stop=stop, end_id=end_token_id,
                                                 want_logits=want_logits, rows_per_workgroup=rows_per_workgroup)
