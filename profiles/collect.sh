@@ -12,4 +12,7 @@ python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python bench.py --steps 20 --warmup 3 > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python bench.py --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- python bench.py --steps 3 --warmup 1 > $OUT/write.log 2>&1
+# matrix-pipe busy cycles (summed over all SIMDs) and the GPU-active clock count (summed over the 8 XCDs)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o p -- python bench.py --steps 3 --warmup 1 > $OUT/mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_train -o p -- python bench.py --mode train --steps 3 --warmup 1 > $OUT/mfma_train.log 2>&1
 find $OUT -name "*.csv" | head -20

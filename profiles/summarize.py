@@ -21,7 +21,7 @@ STAGE = {  # kernel-name fragment -> bench stage, all loads 16-byte wide?
     "decode_group_kernel": ("decode", False), "decode_kernel": ("decode", True),
     "conv3x3_smallk_bf16x3_kernel": ("conv0", False), "conv3x3_bf16x3_kernel<2>": ("conv1", False),
     "conv3x3_bf16x3_kernel<1>": ("conv2", False), "conv3x3_bf16x3_kernel<4>": ("conv2", False),
-    "linear_bf16x3_kernel": ("fc", True), "splitk_reduce_kernel": ("fc_reduce", False),
+    "gemm_bf16x3_kernel<true, true>": ("fc", True), "splitk_reduce_kernel": ("fc_reduce", False),
 }
 
 def per_kernel(path, counter):
@@ -49,5 +49,34 @@ for stage, d in out["raw_kb"].items():
     fetch = d.get("FETCH_SIZE", 0.0) * 1024 * (2 if wide else 1)
     out[stage] = int(fetch + d.get("WRITE_SIZE", 0.0) * 1024)
     out.setdefault("_fetch_doubled", {})[stage] = wide
+# matrix-pipe utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the
+# 8 XCDs (MI355X_MICROARCH.md): util = busy / (GUI_ACTIVE / 8 * 1024); clock = GUI_ACTIVE / 8 / kernel time
+def mfma_table(sub, dst_name):
+    path = f"{src}/{sub}/p_counter_collection.csv"
+    if not os.path.exists(path):
+        return
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            acc[row["Kernel_Name"]]["ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    rows = []
+    for k, d in acc.items():
+        busy, gui = d.get("SQ_VALU_MFMA_BUSY_CYCLES"), d.get("GRBM_GUI_ACTIVE")
+        if not busy or not gui or sum(busy) == 0:
+            continue
+        b, g = sum(busy) / len(busy), sum(gui) / len(gui)
+        ns = sum(d["ns"]) / len(d["ns"])
+        rows.append((k[:110], len(busy), ns / 1e3, b, g, b / (g / 8 * 1024), g / 8 / ns))
+    with open(f"{dst}/{dst_name}", "w") as f:
+        f.write("kernel,launches,avg_us_under_pmc,mfma_busy_cycles,gui_active,mfma_util,clock_ghz\n")
+        for r in sorted(rows, key=lambda r: -r[2]):
+            f.write(f"\"{r[0]}\",{r[1]},{r[2]:.1f},{r[3]:.0f},{r[4]:.0f},{r[5]:.4f},{r[6]:.3f}\n")
+    print(dst_name)
+    for r in sorted(rows, key=lambda r: -r[2])[:8]:
+        print(f"  {r[0][:70]:70s} {r[2]:8.1f} us  util {r[5]:.3f}  clock {r[6]:.2f} GHz")
+
+mfma_table("mfma", f"pmc_mfma_busy_{tag}.csv")
+mfma_table("mfma_train", f"pmc_mfma_busy_train_{tag}.csv")
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_") and k != "raw_kb"}, indent=1))
