@@ -1038,7 +1038,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
     // grouped kernel: 4 workgroups share 4 rows, weights fully on chip (decode_group.inc.h)
     static const bool group_off = getenv("I2L_DECODE_GROUP") != nullptr && atoi(getenv("I2L_DECODE_GROUP")) == 0;
     if (!group_off && rows_per_wg == 0 && lo.xchg_bytes && select == I2L_SELECT_LOGITS && !h0 && !h_out && !c_out &&
-        steps >= 8 && steps < (1 << 30)) {
+        steps >= 8 && steps <= 65000) {   // the candidate granule carries step + 1 in 16 bits
         GroupParams gp{};
         gp.w = p.w; gp.B = rows; gp.T = steps; gp.n_groups = lo.n_groups;
         gp.tok0 = tok0; gp.forced = forced; gp.ids = ids_out; gp.logits = logits_out;
