@@ -31,6 +31,8 @@ struct GemmArgs {
     float alpha;
     int accumulate;           // C += result instead of C = result
     int split_bf16;           // allow the split-bf16 matrix-core kernel (fp32-grade, not an fmaf chain); gemm.hip
+    int conv_h, conv_w;       // > 0 (split-bf16 kernel only): W is an implicit im2col^T of a (Cin, conv_h, conv_w) image per
+                              // operand pair: W(n = ci*9 + tap, k = y*conv_w + x) = img[ci][y + tap/3 - 1][x + tap%3 - 1], 0 outside
 };
 static inline GemmArgs gemm_args() {
     GemmArgs g{};
@@ -39,6 +41,7 @@ static inline GemmArgs gemm_args() {
 }
 size_t i2l_gemm_workspace_bytes(int M, int N, int K, int nz = 1);
 int i2l_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s);
+bool i2l_gemm_split_bf16_ok(const GemmArgs& g);   // would i2l_gemm run this on the split-bf16 kernel?
 
 // ---- 3 x bf16 split conv block on the bf16 matrix cores (conv_bf16x3.hip); inference forward of blocks with
 //      Cin % 16 == 0 and Cout % 64 == 0 unless I2L_CONV_EXACT_FP32=1

@@ -544,6 +544,10 @@ BwdLayout bwd_layout(int B, int Cin, int H, int W, int Cout) {
     o.dyp = off; off += i2l_align((size_t)B * Cout * HW * sizeof(float));
     o.colT = off; off += i2l_align((size_t)o.chunk * Cin * 9 * HW * sizeof(float));
     o.gemm_bytes = i2l_gemm_workspace_bytes(Cout, Cin * 9, (int)HW, o.chunk);
+    {   // the whole batch in one implicit-im2col GEMM (split-bf16 kernel)
+        const size_t all = i2l_gemm_workspace_bytes(Cout, Cin * 9, (int)HW, B);
+        if (all > o.gemm_bytes) o.gemm_bytes = all;
+    }
     o.gemm = off; off += i2l_align(o.gemm_bytes);
     o.wpack_bytes = i2l_conv_workspace_bytes(Cout, Cin);         // data-gradient conv: Cout -> Cin channels
     o.wpack = off; off += i2l_align(o.wpack_bytes);
@@ -588,7 +592,23 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     hipLaunchKernelGGL(plane_sum_final_kernel, dim3(i2l_cdiv(Cout, 64)), dim3(64), 0, s, (const double*)psum, db, B, Cout);
     I2L_CHECK_LAUNCH();
     // weight gradient: dw[co][(ci,tap)] = sum_b sum_pos dyp[b][co][pos] * colT[b][(ci,tap)][pos]
-    for (int b0 = 0; b0 < B; b0 += lo.chunk) {
+    bool wgrad_done = false;
+    {   // one GEMM over the whole batch, the im2col^T operand gathered inside the kernel (no colT image)
+        GemmArgs g = gemm_args();
+        g.A = dyp; g.lda = (long)HW; g.bsa = (long)(Cout * HW);
+        g.W = x; g.ldw = (long)HW; g.bsw = (long)(Cin * HW);
+        g.conv_h = H; g.conv_w = W;
+        g.nz = B;
+        g.split_bf16 = 1;
+        g.C = dw; g.ldc = Cin * 9;
+        g.M = Cout; g.N = Cin * 9; g.K = (int)HW;
+        if (i2l_gemm_split_bf16_ok(g)) {
+            const int rc = i2l_gemm(g, base + lo.gemm, lo.gemm_bytes, s);
+            if (rc != I2L_OK) return rc;
+            wgrad_done = true;
+        }
+    }
+    for (int b0 = 0; b0 < B && !wgrad_done; b0 += lo.chunk) {
         const int nb = B - b0 < lo.chunk ? B - b0 : lo.chunk;
         const size_t total = (size_t)nb * Cin * 9 * HW;
         size_t blocks = (total + 255) / 256;

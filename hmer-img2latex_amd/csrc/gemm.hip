@@ -294,7 +294,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         const size_t oa = (size_t)z * g.bsa, ow = (size_t)z * g.bsw;
         load8(A_KC, pa0 + oa, g.lda, oka0, k0 + a_kg0 * 8, kend, st.a[0][0], st.a[0][1]);
         load8(A_KC, pa1 + oa, g.lda, oka1, k0 + a_kg1 * 8, kend, st.a[1][0], st.a[1][1]);
-        load8(W_KC, pw + ow, g.ldw, okw, k0 + w_kg * 8, kend, st.w[0], st.w[1]);
+        if (g.conv_h > 0) {
+            // implicit im2col^T: row n = n0 + w_row = (ci, tap), 8 consecutive positions k of image z
+            const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+            st.w[0] = zz; st.w[1] = zz;
+            const int n = n0 + w_row, kk = k0 + w_kg * 8;
+            if (okw && kk < kend) {
+                const int ci = n / 9, tap = n - 9 * ci, dyy = tap / 3 - 1, dxx = tap - 3 * (tap / 3) - 1;
+                const float* img = g.W + ow + (size_t)ci * g.conv_h * g.conv_w;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pos = kk + j, yy = pos / g.conv_w, xx = pos - yy * g.conv_w;
+                    const int iy = yy + dyy, ix = xx + dxx;
+                    v[j] = (pos < kend && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w) ? img[(size_t)iy * g.conv_w + ix] : 0.f;
+                }
+                st.w[0] = make_float4(v[0], v[1], v[2], v[3]);
+                st.w[1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        } else {
+            load8(W_KC, pw + ow, g.ldw, okw, k0 + w_kg * 8, kend, st.w[0], st.w[1]);
+        }
     };
     auto commit = [&](const Stage& st) {
         uint4 o[3];
@@ -383,6 +403,7 @@ bool bf16x3_applicable(const GemmArgs& g) {
     if (split_bf16_exact_mode() || g.K < 64 || (g.nz > 1 && (g.K % LBK != 0 || (long)g.nz * g.K > 0x7fffffffl))) return false;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     if (g.a_kc && (!al16(g.A) || g.lda % 4 != 0 || g.K % 8 != 0)) return false;
+    if (g.conv_h > 0) return g.w_kc && g.K == g.conv_h * g.conv_w;     // gathered W: no alignment requirement
     if (g.w_kc && (!al16(g.W) || g.ldw % 4 != 0 || g.K % 8 != 0)) return false;
     return true;
 }
@@ -412,6 +433,12 @@ int run_bf16x3(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s) {
 }
 
 }  // namespace
+
+bool i2l_gemm_split_bf16_ok(const GemmArgs& g0) {
+    GemmArgs g = g0;
+    if (g.nz < 1) g.nz = 1;
+    return g.split_bf16 && bf16x3_applicable(g);
+}
 
 size_t i2l_gemm_workspace_bytes(int M, int N, int K, int nz) {
     int ks, kc;
