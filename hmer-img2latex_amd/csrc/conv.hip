@@ -492,6 +492,35 @@ __global__ __launch_bounds__(256) void unpool_relu_bwd_kernel(const float* __res
     }
 }
 
+// same, four output columns (two pooling windows) per thread and 16-byte stores; needs W % 4 == 0
+__global__ __launch_bounds__(256) void unpool_relu_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               const unsigned char* __restrict__ amax,
+                                                               float* __restrict__ dyp, size_t planes, int H, int W,
+                                                               int Hp, int Wp) {
+    const int W4 = W >> 2;
+    const size_t total = planes * H * W4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t prow = i / W4;                    // (plane, yy)
+        const int x4 = (int)(i - prow * W4);
+        const size_t pl = prow / H;
+        const int yy = (int)(prow - pl * H);
+        const int py = yy >> 1, ry = yy & 1;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (py < Hp) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int px = 2 * x4 + e;
+                if (px < Wp) {
+                    const size_t o = (pl * Hp + py) * Wp + px;
+                    const int am = (int)amax[o];
+                    if (y[o] > 0.f && (am >> 1) == ry) v[2 * e + (am & 1)] = dy[o];
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(dyp + (prow * W + 4 * (size_t)x4)) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // colT[b][(ci*9+tap)][pos] = x[b][ci][y+ky-1][x+kx-1] (0 outside) for a chunk of images
 __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ x, float* __restrict__ colT, int nb,
                                                        int Cin, int H, int W) {
@@ -581,8 +610,15 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         const size_t total = (size_t)B * Cout * HW;
         size_t blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(unpool_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, y, argmax, dyp,
-                           (size_t)B * Cout, H, W, Hp, Wp);
+        if (W % 4 == 0 && reinterpret_cast<uintptr_t>(dyp) % 16 == 0) {
+            size_t b4 = (total / 4 + 255) / 256;
+            if (b4 > 16384) b4 = 16384;
+            hipLaunchKernelGGL(unpool_relu_bwd4_kernel, dim3((unsigned)b4), dim3(256), 0, s, dy, y, argmax, dyp,
+                               (size_t)B * Cout, H, W, Hp, Wp);
+        } else {
+            hipLaunchKernelGGL(unpool_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, y, argmax, dyp,
+                               (size_t)B * Cout, H, W, Hp, Wp);
+        }
         I2L_CHECK_LAUNCH();
     }
     if (B > 65535) return I2L_ERR_UNSUPPORTED;
