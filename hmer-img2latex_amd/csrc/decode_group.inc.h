@@ -357,3 +357,4 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
     }
     if (ids_row) for (int tt = t + tid; tt < T; tt += GNT) ids_row[tt] = -1;   // steps never executed (sticky stop)
 }
+#undef I2L_STAMP
