@@ -7,6 +7,7 @@
 // Parity status: UNPINNED (torchvision is not installed and the reference fetches remote weights;
 // SURVEY.md 8c) -- tests compare against this repo's own fp32 restatement of the v1.5 architecture.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -200,6 +201,302 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(BfGemm g) {
     }
 }
 
+// ------------------------------------------------------------------ ring-buffered bf16 GEMM
+// Same contract as gemm_bf16_kernel for K % BK == 0.  The single-buffered kernel above spends a full
+// memory round trip per 64-deep K tile (about 1.5 us against 0.25 us of MFMA work on the 3x3 layers);
+// here the operand tiles go global -> LDS directly (global_load_lds_dwordx4, no registers) into a ring of
+// NS stages, NS-1 tiles ahead of the MFMAs, with one raw barrier per K tile and counted vmcnt waits so the
+// loads stay in flight across the barriers.  The LDS image of such a load is lane-linear (1 KiB per wave
+// instruction), so the bank-conflict swizzle (16-byte chunk ^ row bits) is applied to the per-lane SOURCE
+// address and again to the fragment reads.  Padding taps of the implicit-GEMM gather read a zero chunk.
+__device__ __attribute__((aligned(16))) uint4 g_zero_chunk[1];
+
+template <int BK>
+__device__ __forceinline__ int ring_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NTW, int BK, int NS, bool CONV, bool RES>
+__global__ __launch_bounds__(256) void gemm_bf16_ring_kernel(BfGemm g, int nb_n, int total_tiles) {
+    constexpr int BN = 64 * NTW, CH = BK / 8, ROWB = BK * 2;
+    constexpr int A_BYTES = GM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+    constexpr int NLA = A_BYTES / 4096, NLW = W_BYTES / 4096, NL = NLA + NLW;   // loads per thread per stage
+    constexpr int CLD = BN + 8, CHUNKS = BN / 8, NRES = GM * CHUNKS / 256;
+    static_assert(NS >= 2 && NS <= 4 && NL * (NS - 2) < 64, "ring depth");
+    static_assert(GM * CLD * 2 <= NS * STAGE, "staged C tile must fit in the ring");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int t = blockIdx.x;
+    if ((total_tiles & 7) == 0) t = (t & 7) * (total_tiles >> 3) + (t >> 3);   // tiles sharing A rows on one XCD
+    const int mb = t / nb_n;
+    const int n0 = (t - mb * nb_n) * BN, m0 = mb * GM;
+
+    // residual tile: requested first, consumed in the epilogue
+    uint4 rres[NRES];
+    if constexpr (RES) {
+#pragma unroll
+        for (int j = 0; j < NRES; ++j) {
+            const int idx = tid + j * 256;
+            const int ml = idx / CHUNKS, c8 = (idx - ml * CHUNKS) * 8;
+            const int m = min(m0 + ml, g.M - 1), n = min(n0 + c8, g.N - 8);
+            rres[j] = *reinterpret_cast<const uint4*>(g.res + (size_t)m * g.ldr + n);
+        }
+    }
+
+    // per-thread sources of the NL 16-byte pieces of a stage
+    const bf16_t* srcA[NLA];
+    const bf16_t* srcW[NLW];
+    int py[NLA], px[NLA];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int s = i * 256 + tid, row = s / CH, c = (s % CH) ^ ring_swz<BK>(row);
+        const int m = min(m0 + row, g.M - 1);
+        if constexpr (CONV) {
+            const int xo = m % g.Wo, tt = m / g.Wo;
+            const int b = tt / g.Ho;
+            py[i] = (tt - b * g.Ho) * g.stride - g.pad;
+            px[i] = xo * g.stride - g.pad;
+            srcA[i] = g.A + ((size_t)b * g.iH * g.iW) * g.Cin + c * 8;
+        } else {
+            py[i] = px[i] = 0;
+            srcA[i] = g.A + (size_t)m * g.lda + c * 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+        const int s = i * 256 + tid, row = s / CH, c = (s % CH) ^ ring_swz<BK>(row);
+        srcW[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+    }
+    int is_k0 = 0, is_c0 = 0, is_ky = 0, is_kx = 0, is_slot = 0;      // state of the next stage to issue
+    const bf16_t* const zero_chunk = reinterpret_cast<const bf16_t*>(g_zero_chunk);
+    auto issue = [&]() {
+        unsigned char* base = ring + is_slot * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const bf16_t* p;
+            if constexpr (CONV) {
+                const int yi = py[i] + is_ky, xi = px[i] + is_kx;
+                const bool in = (unsigned)yi < (unsigned)g.iH && (unsigned)xi < (unsigned)g.iW;
+                const int off = (yi * g.iW + xi) * g.Cin + is_c0;          // inside one image: fits an int
+                p = in ? srcA[i] + off : zero_chunk;
+            } else {
+                p = srcA[i] + is_k0;
+            }
+            glds16(p, base + i * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) glds16(srcW[i] + is_k0, base + A_BYTES + i * 4096);
+        is_k0 += BK;
+        is_c0 += BK;
+        if (CONV && is_c0 >= g.Cin) {
+            is_c0 = 0;
+            if (++is_kx == g.kw) { is_kx = 0; ++is_ky; }
+        }
+        if (++is_slot == NS) is_slot = 0;
+    };
+
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment read offsets inside a stage: row * ROWB + ((chunk ^ swz(row)) << 4), chunk = 2*ks + lh
+    int offA[2], qA[2], offB[NTW], qB[NTW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int row = wm * 64 + a * 32 + li;
+        offA[a] = row * ROWB;
+        qA[a] = lh ^ ring_swz<BK>(row);
+    }
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) {
+        const int row = wn * 32 * NTW + b * 32 + li;
+        offB[b] = A_BYTES + row * ROWB;
+        qB[b] = lh ^ ring_swz<BK>(row);
+    }
+
+    const int KT = g.K / BK;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) issue();
+    int slot = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int rem = KT - 1 - kt;                       // stages issued after this one
+        if (NS >= 4 && rem >= 2) wait_vm<NL * 2>();
+        else if (NS >= 3 && rem >= 1) wait_vm<NL>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                      // stage kt landed for every wave; slot kt-1 is free
+        const unsigned char* st = ring + slot * STAGE;
+        bf16x8 a[BK / 16][2], b[BK / 16][NTW];             // the whole tile's fragments, then the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+                a[ks][x] = *reinterpret_cast<const bf16x8*>(st + offA[x] + (((2 * ks) ^ qA[x]) << 4));
+#pragma unroll
+            for (int x = 0; x < NTW; ++x)
+                b[ks][x] = *reinterpret_cast<const bf16x8*>(st + offB[x] + (((2 * ks) ^ qB[x]) << 4));
+        }
+        if (kt + NS - 1 < KT) issue();
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][mt], b[ks][nt], acc[mt][nt], 0, 0, 0);
+        if (++slot == NS) slot = 0;
+    }
+    __syncthreads();                                       // every wave is done with the ring
+    // epilogue: scaled tile staged in LDS as bf16, then whole rows at 16 bytes per lane (N % 8 == 0)
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(ring);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int nl = wn * 32 * NTW + nt * 32 + li;
+        const int n = n0 + nl;
+        const float sc = (g.scale && n < g.N) ? g.scale[n] : 1.f, bi = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[mt][nt][r] * sc + bi;
+                if (g.relu && !RES) v = fmaxf(v, 0.f);
+                Cs[ml * CLD + nl] = f2bf(v);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NRES; ++j) {
+        const int idx = tid + j * 256;
+        const int ml = idx / CHUNKS, c8 = (idx - ml * CHUNKS) * 8;
+        const int m = m0 + ml, n = n0 + c8;
+        if (m >= g.M || n >= g.N) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(&Cs[ml * CLD + c8]);
+        if constexpr (RES) {
+            bf16_t* hv = reinterpret_cast<bf16_t*>(&v);
+            const bf16_t* hr = reinterpret_cast<const bf16_t*>(&rres[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(hv[e]) + bf2f(hr[e]);
+                if (g.relu) f = fmaxf(f, 0.f);
+                hv[e] = f2bf(f);
+            }
+        }
+        *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = v;
+    }
+}
+
+// ------------------------------------------------------------------ fused stem (7x7, stride 2, pad 3, 3 -> 64)
+// conv1 + bn1 + relu straight from the fp32 NCHW images to NHWC bf16: no im2col image in HBM (that image is
+// 420 MB at B=256 and cost 0.6 ms to write and read back).  A workgroup walks 4x32-pixel output tiles, one
+// output row per wave.  The 13x69 input window of a tile sits in LDS as bf16; the K axis is ordered
+// (ci, ky, kx) with kx padded 7 -> 8, so one 8-wide MFMA operand chunk is 8 consecutive window columns
+// (four aligned 4-byte LDS reads, columns 2*px .. 2*px+7; the 8th tap has zero weight).
+constexpr int ST_TH = 4, ST_TW = 32;
+constexpr int ST_WR = (ST_TH - 1) * 2 + 7;           // 13 window rows
+constexpr int ST_WC = (ST_TW - 1) * 2 + 7;           // 69 window columns
+constexpr int ST_WS = 72;                            // window row stride (column 69 = the zero tap's operand)
+constexpr int ST_Q = 22;                             // chunks of 8: 21 (ci, ky) rows + 1 all-zero
+constexpr int ST_K = ST_Q * 8;                       // 176 = 11 MFMA k-steps
+constexpr int ST_WLD = ST_K + 8;                     // filter row stride in LDS: 368 B = odd multiple of 16
+constexpr int ST_CLD = 72;
+
+__global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp, int Kp,
+                                                         const float* __restrict__ scale, const float* __restrict__ bias,
+                                                         bf16_t* __restrict__ y, int H, int W, int Ho, int Wo, int tiles_x,
+                                                         int tiles_y, int n_tiles, int relu) {
+    __shared__ __attribute__((aligned(16))) bf16_t win[3 * ST_WR * ST_WS];
+    __shared__ __attribute__((aligned(16))) bf16_t wl[64 * ST_WLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Cs[ST_TH * ST_TW * ST_CLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // filter image: wl[n][(ci*7 + ky)*8 + kx] = wp[n][(ky*7 + kx)*3 + ci]   (packed layout of pack_conv_bf16_kernel)
+    for (int i = tid; i < 64 * ST_K; i += 256) {
+        const int n = i / ST_K, k = i - n * ST_K;
+        const int q = k >> 3, kx = k & 7;
+        bf16_t v = 0;
+        if (q < 21 && kx < 7) {
+            const int ci = q / 7, ky = q - ci * 7;
+            v = wp[(size_t)n * Kp + (ky * 7 + kx) * 3 + ci];
+        }
+        wl[n * ST_WLD + k] = v;
+    }
+    float sc[2], bi[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        sc[nt] = scale[nt * 32 + li];
+        bi[nt] = bias[nt * 32 + li];
+    }
+    const int abase = (2 * wave) * ST_WS + 2 * li;           // window element of this lane's pixel, tap (0, 0)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, t2 = tile / tiles_x;
+        const int ty = t2 % tiles_y, b = t2 / tiles_y;
+        const int yo0 = ty * ST_TH, xo0 = tx * ST_TW;
+        const int yi0 = yo0 * 2 - 3, xi0 = xo0 * 2 - 3;
+        __syncthreads();                                     // the previous tile is out of win / Cs (first pass: wl is complete)
+        for (int i = tid; i < 3 * ST_WR * ST_WS; i += 256) {
+            const int c = i % ST_WS, rr = i / ST_WS;
+            const int r = rr % ST_WR, ci = rr / ST_WR;
+            const int yi = yi0 + r, xi = xi0 + c;
+            float v = 0.f;
+            if (c < ST_WC && (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W)
+                v = x[(((size_t)b * 3 + ci) * H + yi) * W + xi];
+            win[i] = f2bf(v);
+        }
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < ST_K / 16; ++ks) {
+            // chunk q = 2*ks + lh is window row (ci*13 + ky); the all-zero chunk 21 re-reads chunk 20's (finite) data
+            constexpr int Q0 = 0;
+            const int q0 = 2 * ks + Q0, q1 = (2 * ks + 1 > 20) ? 20 : 2 * ks + 1;
+            const int rq = lh ? ((q1 / 7) * ST_WR + q1 % 7) : ((q0 / 7) * ST_WR + q0 % 7);
+            const unsigned* pw = reinterpret_cast<const unsigned*>(win + abase + rq * ST_WS);
+            union { unsigned u[4]; bf16x8 v; } a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a.u[e] = pw[e];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const bf16x8 bb = *reinterpret_cast<const bf16x8*>(&wl[(nt * 32 + li) * ST_WLD + ks * 16 + lh * 8]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bb, acc[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = wave * ST_TW + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[nt][r] * sc[nt] + bi[nt];
+                if (relu) v = fmaxf(v, 0.f);
+                Cs[pix * ST_CLD + nt * 32 + li] = f2bf(v);
+            }
+        __syncthreads();
+        for (int idx = tid; idx < ST_TH * ST_TW * 8; idx += 256) {
+            const int pix = idx >> 3, c8 = (idx & 7) * 8;
+            const int yo = yo0 + (pix >> 5), xo = xo0 + (pix & 31);
+            if (yo < Ho && xo < Wo)
+                *reinterpret_cast<uint4*>(y + (((size_t)b * Ho + yo) * Wo + xo) * 64 + c8) =
+                    *reinterpret_cast<const uint4*>(&Cs[pix * ST_CLD + c8]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ layout / packing kernels
 // wp[co][(tap*Cin + ci)] (K padded to Kp with zeros) = w[co][ci][tap]; scale/bias = folded BatchNorm
 __global__ __launch_bounds__(256) void pack_conv_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp,
@@ -365,6 +662,52 @@ PackLayout pack_layout(int Cout, int Cin, int kh, int kw) {
 }
 }  // namespace
 
+namespace {
+bool stem_fused_enabled() {
+    static const bool on = [] { const char* e = getenv("I2L_RESNET_STEM_FUSED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+bool stem_shape(int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    return Cin == 3 && Cout == 64 && kh == 7 && kw == 7 && stride == 2 && pad == 3;
+}
+bool ring_enabled() {
+    static const bool on = [] { const char* e = getenv("I2L_RESNET_RING"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// Stages of the operand ring (I2L_RESNET_RING_DEPTH overrides, 2..4).  Two stages are 64 KB of LDS, so two
+// workgroups share a CU and cover each other's waits: measured faster than a deeper ring on every layer
+// that has more tiles than CUs.  With at most one tile per CU only the ring hides latency: 4 stages.
+int ring_depth(int kt, long tiles) {
+    static const int forced = [] { const char* e = getenv("I2L_RESNET_RING_DEPTH"); return e ? atoi(e) : 0; }();
+    if (forced >= 2 && forced <= 4) return forced;
+    return (tiles <= 256 && kt >= 4) ? 4 : 2;
+}
+template <int NTW, int NS, bool CONV, bool RES>
+int launch_ring4(const BfGemm& g, int nb_n, int total, hipStream_t s) {
+    constexpr int BK = 64, lds = NS * (GM + 64 * NTW) * BK * 2;
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return I2L_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES>), dim3(total), dim3(256), lds, s, g, nb_n, total);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+template <int NTW, int NS>
+int launch_ring2(const BfGemm& g, int nb_n, int total, hipStream_t s) {
+    if (g.conv)
+        return g.res ? launch_ring4<NTW, NS, true, true>(g, nb_n, total, s)
+                     : launch_ring4<NTW, NS, true, false>(g, nb_n, total, s);
+    return g.res ? launch_ring4<NTW, NS, false, true>(g, nb_n, total, s)
+                 : launch_ring4<NTW, NS, false, false>(g, nb_n, total, s);
+}
+template <int NTW>
+int launch_ring(const BfGemm& g, int depth, int nb_n, int total, hipStream_t s) {
+    return depth == 4 ? launch_ring2<NTW, 4>(g, nb_n, total, s)
+         : depth == 3 ? launch_ring2<NTW, 3>(g, nb_n, total, s) : launch_ring2<NTW, 2>(g, nb_n, total, s);
+}
+}  // namespace
+
 extern "C" size_t i2l_conv_bf16_packed_bytes(int Cout, int Cin, int kh, int kw) {
     if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return 0;
     return pack_layout(Cout, Cin, kh, kw).total;
@@ -398,7 +741,8 @@ extern "C" size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, in
     const int Kp = i2l_cdiv(kh * kw * Cin, 8) * 8;
     const bool direct = kh == 1 && kw == 1 && stride == 1 && pad == 0 && Cin % 8 == 0;
     const bool implicit = Cin % 64 == 0;                   // NHWC input gathered inside the GEMM (no im2col image)
-    return (direct || implicit) ? 256 : i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
+    const bool stem = stem_fused_enabled() && stem_shape(Cin, Cout, kh, kw, stride, pad);
+    return (direct || implicit || stem) ? 256 : i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
 }
 
 // y = act( BN(conv(x, w)) + residual ), NHWC bf16 in/out (x may instead be the NCHW fp32 image batch);
@@ -425,6 +769,16 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     bf16_t* col = static_cast<bf16_t*>(workspace);
     const size_t M = (size_t)B * Ho * Wo;
     if (M > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
+    if (x_is_nchw_f32 && !residual && stem_fused_enabled() && stem_shape(Cin, Cout, kh, kw, stride, pad)) {
+        const int tiles_x = i2l_cdiv(Wo, ST_TW), tiles_y = i2l_cdiv(Ho, ST_TH);
+        const long n_tiles = (long)B * tiles_x * tiles_y;
+        if (n_tiles > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
+        const int grid = (int)(n_tiles < 768 ? n_tiles : 768);          // 3 workgroups per CU walk the tiles
+        hipLaunchKernelGGL(stem_conv7_kernel, dim3(grid), dim3(256), 0, s, static_cast<const float*>(x), wp, Kp, scale,
+                           bias, static_cast<bf16_t*>(y), H, W, Ho, Wo, tiles_x, tiles_y, (int)n_tiles, relu);
+        I2L_CHECK_LAUNCH();
+        return I2L_OK;
+    }
     BfGemm g{};
     const bool direct = !x_is_nchw_f32 && kh == 1 && kw == 1 && stride == 1 && pad == 0;
     const bool implicit = !x_is_nchw_f32 && !direct && Cin % 64 == 0;
@@ -453,6 +807,13 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     g.C = static_cast<bf16_t*>(y); g.ldc = Cout;
     g.M = (int)M; g.N = Cout; g.K = Kp; g.relu = relu;
     const int gn = Cout <= 64 ? 64 : 128;                  // narrow tile for the 64-channel layers (no wasted MFMAs)
+    if (ring_enabled() && (direct || implicit) && Kp % 64 == 0) {
+        const int nb_n = i2l_cdiv(Cout, gn), nb_m = i2l_cdiv((int)M, GM);
+        const long total = (long)nb_n * nb_m;
+        const int depth = ring_depth(Kp / 64, total);
+        if (total > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
+        return gn == 64 ? launch_ring<1>(g, depth, nb_n, (int)total, s) : launch_ring<2>(g, depth, nb_n, (int)total, s);
+    }
     dim3 grid(i2l_cdiv(Cout, gn), i2l_cdiv((int)M, GM));
     if (grid.y > 65535) return I2L_ERR_UNSUPPORTED;
     if (gn == 64) hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, dim3(256), 0, s, g);

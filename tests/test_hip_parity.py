@@ -308,6 +308,58 @@ def test_greedy_pipeline_matches_serial():
     pipe.drain()
 
 
+# (B, H, W, Cin, Cout, k, stride, pad, residual, nchw fp32 images): every bf16 conv path of the ResNet trunk --
+# direct 1x1 and implicit-GEMM 3x3 / strided 1x1 through the ring-buffered kernel (2 stages below 4 K tiles,
+# 4 stages from there; 64- and 128-column tiles; ragged M and N), the fused 7x7 stem with ragged tiles, and the
+# im2col fallbacks (Cin % 64 != 0, unusual stem)
+BF16_CONV_CASES = [
+    (2, 9, 13, 64, 64, 3, 1, 1, 0, 0), (3, 8, 10, 64, 256, 1, 1, 0, 1, 0), (2, 7, 9, 256, 64, 1, 1, 0, 0, 0),
+    (2, 10, 14, 128, 128, 3, 2, 1, 0, 0), (2, 10, 14, 256, 512, 1, 2, 0, 0, 0), (1, 5, 7, 512, 512, 3, 1, 1, 1, 0),
+    (5, 6, 6, 128, 72, 1, 1, 0, 1, 0), (2, 6, 6, 64, 200, 3, 1, 1, 1, 0), (1, 4, 5, 2048, 512, 1, 1, 0, 0, 0),
+    (3, 18, 75, 3, 64, 7, 2, 3, 0, 1), (2, 64, 320, 3, 64, 7, 2, 3, 0, 1), (2, 12, 12, 3, 32, 7, 2, 3, 0, 1),
+    (2, 9, 9, 32, 64, 3, 1, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CONV_CASES)
+def test_bf16_conv_bn_act_vs_torch(case):
+    """i2l_conv_bn_act_bf16_fwd against fp32 torch on the same bf16-rounded operands (encoder.py:132-249 trunk ops):
+    the only differences are fp32 summation order and the final rounding to bf16 (2^-8 relative)."""
+    B, H, W, Cin, Cout, k, s, pd, res, nchw = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    mean, var = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    x = torch.randn(B, Cin, H, W, generator=g)
+    Ho, Wo = (H + 2 * pd - k) // s + 1, (W + 2 * pd - k) // s + 1
+    r = torch.randn(B, Cout, Ho, Wo, generator=g) if res else None
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    scale = gamma / torch.sqrt(var + 1e-5)
+    want = torch.nn.functional.conv2d(rnd(x), rnd(w), stride=s, padding=pd) * scale[None, :, None, None] \
+        + (beta - mean * scale)[None, :, None, None]
+    if res:
+        want = rnd(want) + rnd(r)           # the kernel rounds the scaled tile once before adding the residual
+    want = torch.relu(want)
+    nb = L.i2l_conv_bf16_packed_bytes(Cout, Cin, k, k)
+    packed = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dv = lambda t: t.contiguous().to(DEV)
+    wd, gd, bd, md, vd = dv(w), dv(gamma), dv(beta), dv(mean), dv(var)
+    _lib.check(L.i2l_conv_bn_bf16_pack(wd.data_ptr(), gd.data_ptr(), bd.data_ptr(), md.data_ptr(), vd.data_ptr(), 1e-5,
+                                       packed.data_ptr(), nb, Cout, Cin, k, k, _lib.stream_ptr()), "pack")
+    xd = dv(x) if nchw else dv(x.permute(0, 2, 3, 1)).to(torch.bfloat16)
+    rd = dv(r.permute(0, 2, 3, 1)).to(torch.bfloat16) if res else None
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd)
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=DEV)
+    _lib.check(L.i2l_conv_bn_act_bf16_fwd(xd.data_ptr(), nchw, packed.data_ptr(), _lib.ptr(rd), y.data_ptr(), B, H, W, Cin, Cout,
+                                          k, k, s, pd, 1, ws.data_ptr(), wsb, _lib.stream_ptr()), "conv_bn_act_bf16_fwd")
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    assert float((err - 2.0 ** -7 * want.abs()).max()) <= 2e-3, float(err.max())
+
+
 @pytest.mark.parametrize("model_name,hw", [("resnet18", (32, 64)), ("resnet50", (64, 96))])
 def test_resnet_encoder_vs_oracle(model_name, hw):
     """bf16 MFMA trunk against the fp32 restatement (parity unpinned: no reference output exists)."""
