@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_ring_kernel(BfGemm g, int nb_n,
     constexpr int A_BYTES = GM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
     constexpr int NLA = A_BYTES / 4096, NLW = W_BYTES / 4096, NL = NLA + NLW;   // loads per thread per stage
     constexpr int CLD = BN + 8, CHUNKS = BN / 8, NRES = GM * CHUNKS / 256;
-    static_assert(NS >= 2 && NS <= 4 && NL * (NS - 2) < 64, "ring depth");
+    static_assert(NS >= 2 && NS <= 6 && NL * (NS - 2) < 64, "ring depth");
     static_assert(GM * CLD * 2 <= NS * STAGE, "staged C tile must fit in the ring");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -332,8 +332,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_ring_kernel(BfGemm g, int nb_n,
         if (s < KT) issue();
     int slot = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const int rem = KT - 1 - kt;                       // stages issued after this one
-        if (NS >= 4 && rem >= 2) wait_vm<NL * 2>();
+        const int rem = KT - 1 - kt;                       // stages issued after this one: up to NS-2 stay in flight
+        if (NS >= 6 && rem >= 4) wait_vm<NL * 4>();
+        else if (NS >= 5 && rem >= 3) wait_vm<NL * 3>();
+        else if (NS >= 4 && rem >= 2) wait_vm<NL * 2>();
         else if (NS >= 3 && rem >= 1) wait_vm<NL>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();                      // stage kt landed for every wave; slot kt-1 is free
@@ -440,21 +442,35 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict
         bi[nt] = bias[nt * 32 + li];
     }
     const int abase = (2 * wave) * ST_WS + 2 * li;           // window element of this lane's pixel, tap (0, 0)
+    constexpr int NWIN = (3 * ST_WR * ST_WS + 255) / 256;    // window elements per thread
+    float nxt[NWIN];                                         // the next tile's window, in flight during this tile's math
+    auto fetch_window = [&](int tile) {
+        const int tx = tile % tiles_x, t2 = tile / tiles_x;
+        const int ty = t2 % tiles_y, b = t2 / tiles_y;
+        const int yi0 = ty * ST_TH * 2 - 3, xi0 = tx * ST_TW * 2 - 3;
+#pragma unroll
+        for (int j = 0; j < NWIN; ++j) {
+            const int i = tid + j * 256;
+            const int c = i % ST_WS, rr = i / ST_WS;
+            const int r = rr % ST_WR, ci = rr / ST_WR;
+            const int yi = yi0 + r, xi = xi0 + c;
+            nxt[j] = 0.f;
+            if (ci < 3 && c < ST_WC && (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W)
+                nxt[j] = x[(((size_t)b * 3 + ci) * H + yi) * W + xi];
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) fetch_window(blockIdx.x);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, t2 = tile / tiles_x;
         const int ty = t2 % tiles_y, b = t2 / tiles_y;
         const int yo0 = ty * ST_TH, xo0 = tx * ST_TW;
-        const int yi0 = yo0 * 2 - 3, xi0 = xo0 * 2 - 3;
         __syncthreads();                                     // the previous tile is out of win / Cs (first pass: wl is complete)
-        for (int i = tid; i < 3 * ST_WR * ST_WS; i += 256) {
-            const int c = i % ST_WS, rr = i / ST_WS;
-            const int r = rr % ST_WR, ci = rr / ST_WR;
-            const int yi = yi0 + r, xi = xi0 + c;
-            float v = 0.f;
-            if (c < ST_WC && (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W)
-                v = x[(((size_t)b * 3 + ci) * H + yi) * W + xi];
-            win[i] = f2bf(v);
+#pragma unroll
+        for (int j = 0; j < NWIN; ++j) {
+            const int i = tid + j * 256;
+            if (i < 3 * ST_WR * ST_WS) win[i] = f2bf(nxt[j]);
         }
+        if (tile + (int)gridDim.x < n_tiles) fetch_window(tile + gridDim.x);
         __syncthreads();
         f32x16 acc[2];
 #pragma unroll
@@ -634,12 +650,28 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __
 // AdaptiveAvgPool2d(1) + Flatten: (B,H,W,C) bf16 -> (B,C) fp32
 __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int B,
                                                            int C, int HW) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i - b * C;
-    float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += bf2f(x[((size_t)b * HW + p) * C + c]);
-    y[i] = s / (float)HW;
+    const int c8n = C / 8;                                   // 8 channels (16 bytes) per thread when C % 8 == 0
+    if (C % 8 == 0) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= B * c8n) return;
+        const int b = i / c8n, c8 = (i - b * c8n) * 8;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < HW; ++p) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * C + c8);
+            const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf2f(h[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[(size_t)b * C + c8 + e] = s[e] / (float)HW;
+        return;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * C; i += gridDim.x * 256) {
+        const int b = i / C, c = i - b * C;
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += bf2f(x[((size_t)b * HW + p) * C + c]);
+        y[i] = s / (float)HW;
+    }
 }
 
 int grid_for(size_t n) {
@@ -679,12 +711,12 @@ bool ring_enabled() {
 // that has more tiles than CUs.  With at most one tile per CU only the ring hides latency: 4 stages.
 int ring_depth(int kt, long tiles) {
     static const int forced = [] { const char* e = getenv("I2L_RESNET_RING_DEPTH"); return e ? atoi(e) : 0; }();
-    if (forced >= 2 && forced <= 4) return forced;
+    if (forced >= 2 && forced <= 5) return forced;
     return (tiles <= 256 && kt >= 4) ? 4 : 2;
 }
-template <int NTW, int NS, bool CONV, bool RES>
+template <int NTW, int BK, int NS, bool CONV, bool RES>
 int launch_ring4(const BfGemm& g, int nb_n, int total, hipStream_t s) {
-    constexpr int BK = 64, lds = NS * (GM + 64 * NTW) * BK * 2;
+    constexpr int lds = NS * (GM + 64 * NTW) * BK * 2;
     static const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -693,18 +725,21 @@ int launch_ring4(const BfGemm& g, int nb_n, int total, hipStream_t s) {
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }
-template <int NTW, int NS>
+template <int NTW, int BK, int NS>
 int launch_ring2(const BfGemm& g, int nb_n, int total, hipStream_t s) {
     if (g.conv)
-        return g.res ? launch_ring4<NTW, NS, true, true>(g, nb_n, total, s)
-                     : launch_ring4<NTW, NS, true, false>(g, nb_n, total, s);
-    return g.res ? launch_ring4<NTW, NS, false, true>(g, nb_n, total, s)
-                 : launch_ring4<NTW, NS, false, false>(g, nb_n, total, s);
+        return g.res ? launch_ring4<NTW, BK, NS, true, true>(g, nb_n, total, s)
+                     : launch_ring4<NTW, BK, NS, true, false>(g, nb_n, total, s);
+    return g.res ? launch_ring4<NTW, BK, NS, false, true>(g, nb_n, total, s)
+                 : launch_ring4<NTW, BK, NS, false, false>(g, nb_n, total, s);
 }
 template <int NTW>
 int launch_ring(const BfGemm& g, int depth, int nb_n, int total, hipStream_t s) {
-    return depth == 4 ? launch_ring2<NTW, 4>(g, nb_n, total, s)
-         : depth == 3 ? launch_ring2<NTW, 3>(g, nb_n, total, s) : launch_ring2<NTW, 2>(g, nb_n, total, s);
+    static const int bk = [] { const char* e = getenv("I2L_RESNET_RING_BK"); return e ? atoi(e) : 64; }();
+    if (bk == 32)
+        return depth >= 5 ? launch_ring2<NTW, 32, 5>(g, nb_n, total, s) : launch_ring2<NTW, 32, 4>(g, nb_n, total, s);
+    return depth == 4 ? launch_ring2<NTW, 64, 4>(g, nb_n, total, s)
+         : depth == 3 ? launch_ring2<NTW, 64, 3>(g, nb_n, total, s) : launch_ring2<NTW, 64, 2>(g, nb_n, total, s);
 }
 }  // namespace
 
@@ -806,7 +841,11 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     g.res = static_cast<const bf16_t*>(residual); g.ldr = Cout;
     g.C = static_cast<bf16_t*>(y); g.ldc = Cout;
     g.M = (int)M; g.N = Cout; g.K = Kp; g.relu = relu;
-    const int gn = Cout <= 64 ? 64 : 128;                  // narrow tile for the 64-channel layers (no wasted MFMAs)
+    int gn = Cout <= 64 ? 64 : 128;                        // narrow tile for the 64-channel layers (no wasted MFMAs)
+    {
+        static const int forced = [] { const char* e = getenv("I2L_RESNET_TILE_N"); return e ? atoi(e) : 0; }();
+        if (forced == 64 || forced == 128) gn = forced;
+    }
     if (ring_enabled() && (direct || implicit) && Kp % 64 == 0) {
         const int nb_n = i2l_cdiv(Cout, gn), nb_m = i2l_cdiv((int)M, GM);
         const long total = (long)nb_n * nb_m;
@@ -834,7 +873,7 @@ extern "C" int i2l_maxpool3x3s2_bf16_fwd(const void* x, void* y, int B, int H, i
 
 extern "C" int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H, int W, int C, i2l_stream_t stream) {
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return I2L_ERR_ARG;
-    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(i2l_cdiv(B * C, 256)), dim3(256), 0, i2l_s(stream),
+    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(i2l_cdiv(C % 8 == 0 ? B * (C / 8) : B * C, 256)), dim3(256), 0, i2l_s(stream),
                        static_cast<const bf16_t*>(x), y, B, C, H * W);
     I2L_CHECK_LAUNCH();
     return I2L_OK;

@@ -89,7 +89,11 @@ int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, cons
  * i2l_conv_bn_bf16_pack is the weight-only preparation (bf16 filter image, BatchNorm folded into
  * scale/bias); its result stays valid until a weight or BatchNorm statistic changes.
  * x is NHWC bf16 (B,H,W,Cin), or the NCHW fp32 image batch when x_is_nchw_f32 != 0 (the stem);
- * residual is NHWC bf16 (B,Ho,Wo,Cout) or NULL; y NHWC bf16 (B,Ho,Wo,Cout). */
+ * residual is NHWC bf16 (B,Ho,Wo,Cout) or NULL; y NHWC bf16 (B,Ho,Wo,Cout).
+ * Kernel choice: K = kh*kw*Cin a multiple of 64 with NHWC bf16 input runs the ring-buffered direct-to-LDS GEMM
+ * (I2L_RESNET_RING=0: the single-buffered kernel); the 7x7 / stride 2 / pad 3 / 3 -> 64 stem on fp32 images runs
+ * the fused stem kernel and needs no workspace (I2L_RESNET_STEM_FUSED=0: im2col image + GEMM); every other
+ * shape goes through an im2col image in the workspace.  All paths compute the same bf16 x bf16 -> fp32 sums. */
 size_t i2l_conv_bf16_packed_bytes(int Cout, int Cin, int kh, int kw);
 int i2l_conv_bn_bf16_pack(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                           const float* bn_var, float bn_eps, void* packed, size_t packed_bytes, int Cout,
