@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_ring_kernel(BfGemm g, int nb_n,
     constexpr int A_BYTES = GM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
     constexpr int NLA = A_BYTES / 4096, NLW = W_BYTES / 4096, NL = NLA + NLW;   // loads per thread per stage
     constexpr int CLD = BN + 8, CHUNKS = BN / 8, NRES = GM * CHUNKS / 256;
-    static_assert(NS >= 2 && NS <= 6 && NL * (NS - 2) < 64, "ring depth");
+    static_assert(NS >= 2 && NS <= 4 && NL * (NS - 2) < 64, "ring depth");
     static_assert(GM * CLD * 2 <= NS * STAGE, "staged C tile must fit in the ring");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -711,7 +711,7 @@ bool ring_enabled() {
 // that has more tiles than CUs.  With at most one tile per CU only the ring hides latency: 4 stages.
 int ring_depth(int kt, long tiles) {
     static const int forced = [] { const char* e = getenv("I2L_RESNET_RING_DEPTH"); return e ? atoi(e) : 0; }();
-    if (forced >= 2 && forced <= 5) return forced;
+    if (forced >= 2 && forced <= 4) return forced;
     return (tiles <= 256 && kt >= 4) ? 4 : 2;
 }
 template <int NTW, int BK, int NS, bool CONV, bool RES>
@@ -735,9 +735,6 @@ int launch_ring2(const BfGemm& g, int nb_n, int total, hipStream_t s) {
 }
 template <int NTW>
 int launch_ring(const BfGemm& g, int depth, int nb_n, int total, hipStream_t s) {
-    static const int bk = [] { const char* e = getenv("I2L_RESNET_RING_BK"); return e ? atoi(e) : 64; }();
-    if (bk == 32)
-        return depth >= 5 ? launch_ring2<NTW, 32, 5>(g, nb_n, total, s) : launch_ring2<NTW, 32, 4>(g, nb_n, total, s);
     return depth == 4 ? launch_ring2<NTW, 64, 4>(g, nb_n, total, s)
          : depth == 3 ? launch_ring2<NTW, 64, 3>(g, nb_n, total, s) : launch_ring2<NTW, 64, 2>(g, nb_n, total, s);
 }
@@ -841,11 +838,7 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     g.res = static_cast<const bf16_t*>(residual); g.ldr = Cout;
     g.C = static_cast<bf16_t*>(y); g.ldc = Cout;
     g.M = (int)M; g.N = Cout; g.K = Kp; g.relu = relu;
-    int gn = Cout <= 64 ? 64 : 128;                        // narrow tile for the 64-channel layers (no wasted MFMAs)
-    {
-        static const int forced = [] { const char* e = getenv("I2L_RESNET_TILE_N"); return e ? atoi(e) : 0; }();
-        if (forced == 64 || forced == 128) gn = forced;
-    }
+    const int gn = Cout <= 64 ? 64 : 128;                  // narrow tile for the 64-channel layers (no wasted MFMAs)
     if (ring_enabled() && (direct || implicit) && Kp % 64 == 0) {
         const int nb_n = i2l_cdiv(Cout, gn), nb_m = i2l_cdiv((int)M, GM);
         const long total = (long)nb_n * nb_m;
