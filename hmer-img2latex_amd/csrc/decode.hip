@@ -390,6 +390,7 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned row
 }
 
 #include "decode_group.inc.h"
+#include "beam_group.inc.h"
 
 // KR / KL > 0 (fast path for R == 1, L == 1, H <= 256: thread j owns hidden unit j for the whole loop):
 // rows [0,KR) of WhhT stay in the thread's registers and rows [KR,KR+KL) in LDS for all steps, so only
@@ -1114,10 +1115,32 @@ int launch_beam(const BeamParams& p, size_t lds, hipStream_t s) {
 
 }  // namespace
 
-extern "C" size_t i2l_beam_workspace_bytes(int images, int beam, int hidden, int layers, int steps) {
-    (void)hidden; (void)layers;
-    if (images <= 0 || beam <= 0 || beam > I2L_MAX_BEAM || steps <= 0) return 0;
+namespace {
+// grouped beam search (beam_group.inc.h): shape and beam widths it is built for
+inline bool beam_group_ok(int beam, int H, int L) { return L == 1 && H == 256 && beam >= 2 && beam <= 6; }
+inline int beam_groups(int images, int beam) { return i2l_cdiv(images, BG_S / beam); }
+inline size_t beam_hist_bytes(int images, int beam, int steps) {
     return i2l_align((size_t)2 * images * steps * beam * sizeof(int32_t));
+}
+template <int K>
+int launch_beam_group(const BeamGroupParams& p, hipStream_t s) {
+    constexpr size_t lds = bg_lds_bytes();
+    static_assert(lds <= 160 * 1024, "beam_group_kernel LDS");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_group_kernel<K>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return I2L_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(beam_group_kernel<K>, dim3(i2l_cdiv(p.n_groups, 8) * 32), dim3(GNT), lds, s, p);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+}  // namespace
+
+extern "C" size_t i2l_beam_workspace_bytes(int images, int beam, int hidden, int layers, int steps) {
+    if (images <= 0 || beam <= 0 || beam > I2L_MAX_BEAM || steps <= 0) return 0;
+    size_t b = beam_hist_bytes(images, beam, steps);
+    if (beam_group_ok(beam, hidden, layers))
+        b += GROUP_STATUS_BYTES + (size_t)i2l_cdiv(beam_groups(images, beam), 8) * 8 * BEAM_XCHG_PER_GROUP;
+    return b;
 }
 
 extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspace, int images, int beam, int steps,
@@ -1133,6 +1156,34 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
     const int V = w->vocab, E = w->embed, H = w->hidden, L = w->layers;
     const Layout lo = make_layout(images, V, E, H, L);
     if (lo.Vp > 64 * 32) return I2L_ERR_UNSUPPORTED;      // top-k exclusion mask: 32 elements per lane
+    hipStream_t s = i2l_s(stream);
+    // grouped kernel: 4 workgroups share 12 beam slots, weights fully on chip (beam_group.inc.h); read per call so
+    // that a caller can fall back after a -3 result
+    const char* genv = getenv("I2L_BEAM_GROUP");
+    const bool group_on = !(genv && atoi(genv) == 0);
+    if (group_on && beam_group_ok(beam, H, L) && V <= 512 && steps <= 65000 &&
+        beam_workspace_bytes >= i2l_beam_workspace_bytes(images, beam, H, L, steps)) {
+        BeamGroupParams gp{};
+        gp.w = step_weights(lo, static_cast<const char*>(workspace), V, H, L);
+        gp.images = images; gp.T = steps; gp.n_groups = beam_groups(images, beam);
+        gp.start_id = start_id; gp.end_id = end_id;
+        gp.tokhist = static_cast<int32_t*>(beam_workspace);
+        gp.parhist = gp.tokhist + (size_t)images * steps * beam;
+        gp.seq_out = seq_out; gp.len_out = len_out; gp.score_out = score_out;
+        char* xb = static_cast<char*>(beam_workspace) + beam_hist_bytes(images, beam, steps);
+        const size_t xbytes = GROUP_STATUS_BYTES + (size_t)i2l_cdiv(gp.n_groups, 8) * 8 * BEAM_XCHG_PER_GROUP;
+        gp.status = reinterpret_cast<unsigned*>(xb);
+        gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
+        if (hipMemsetAsync(xb, 0, xbytes, s) != hipSuccess) return I2L_ERR_LAUNCH;
+        switch (beam) {
+            case 2: return launch_beam_group<2>(gp, s);
+            case 3: return launch_beam_group<3>(gp, s);
+            case 4: return launch_beam_group<4>(gp, s);
+            case 5: return launch_beam_group<5>(gp, s);
+            case 6: return launch_beam_group<6>(gp, s);
+            default: break;
+        }
+    }
     BeamParams p{};
     p.w = step_weights(lo, static_cast<const char*>(workspace), V, H, L);
     p.images = images; p.T = steps; p.start_id = start_id; p.end_id = end_id;
@@ -1141,7 +1192,6 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
     p.seq_out = seq_out; p.len_out = len_out; p.score_out = score_out;
     const size_t lds = beam_lds_bytes(beam, L, H, lo.Vp);
     if (lds > 160 * 1024) return I2L_ERR_UNSUPPORTED;
-    hipStream_t s = i2l_s(stream);
     switch (beam) {
         case 1: return launch_beam<1>(p, lds, s);
         case 2: return launch_beam<2>(p, lds, s);

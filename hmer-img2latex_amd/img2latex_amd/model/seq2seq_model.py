@@ -8,6 +8,7 @@ device->host copy of the ids at the end instead of a sync per step).
 from __future__ import annotations
 
 import ctypes
+import os
 import warnings
 from typing import Dict, List, Optional
 
@@ -135,12 +136,28 @@ class Seq2SeqModel(nn.Module):
         seq = torch.empty((n, max_length + 1), dtype=torch.int32, device=dev)
         ln = torch.empty((n,), dtype=torch.int32, device=dev)
         score = torch.empty((n,), dtype=torch.float64, device=dev)
-        _lib.check(L.i2l_beam_decode(ctypes.byref(w), dec._ws.data_ptr(), n, beam_size, max_length,
-                                     int(start_token_id), int(end_token_id), bws.data_ptr(), nbytes,
-                                     seq.data_ptr(), ln.data_ptr(), score.data_ptr(), _lib.stream_ptr()),
-                   "beam_decode")
-        del keep
+        def launch():
+            _lib.check(L.i2l_beam_decode(ctypes.byref(w), dec._ws.data_ptr(), n, beam_size, max_length,
+                                         int(start_token_id), int(end_token_id), bws.data_ptr(), nbytes,
+                                         seq.data_ptr(), ln.data_ptr(), score.data_ptr(), _lib.stream_ptr()),
+                       "beam_decode")
+        launch()
         seq_h, ln_h = seq.cpu(), ln.cpu()
+        if int(ln_h.min()) <= -3:
+            # the grouped kernel needs its four workgroups resident together; on a GPU shared with other work a
+            # poll can time out (len -3): run the one-workgroup-per-image kernel instead
+            warnings.warn("img2latex_amd: grouped beam search timed out, re-running with one workgroup per image")
+            prev = os.environ.get("I2L_BEAM_GROUP")
+            os.environ["I2L_BEAM_GROUP"] = "0"
+            try:
+                launch()
+            finally:
+                if prev is None:
+                    del os.environ["I2L_BEAM_GROUP"]
+                else:
+                    os.environ["I2L_BEAM_GROUP"] = prev
+            seq_h, ln_h = seq.cpu(), ln.cpu()
+        del keep
         out = [seq_h[j, : int(ln_h[j])].tolist() for j in range(n)]
         if return_scores:
             return out, score.cpu().tolist()

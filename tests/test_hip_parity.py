@@ -246,6 +246,23 @@ def test_beam_search_vs_golden(name):
     assert one == padded_to_lists(d["g4_k5_ids"], d["g4_k5_len"])[2]
 
 
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 6])
+def test_grouped_beam_matches_workgroup_per_image(k, monkeypatch):
+    """beam_group_kernel (4 workgroups share 12 beam slots, weights on chip, per-step exchanges) against beam_kernel
+    (one workgroup per image) at the primary dimensions: same sequences, scores within fp32 log-softmax rounding.
+    37 images: several groups per launch and a last group with unused image slots."""
+    d, cfg, _ = load("primary")
+    m, _ = model_for("primary")
+    bimgs = images(cfg, 37, seed=99 + k, device=DEV)
+    with torch.no_grad():
+        enc = m.encoder(bimgs)
+        got, gs = m.beam_search_batch(enc, START, END, 48, k, return_scores=True)
+        monkeypatch.setenv("I2L_BEAM_GROUP", "0")
+        want, ws = m.beam_search_batch(enc, START, END, 48, k, return_scores=True)
+    assert got == want
+    assert np.allclose(gs, ws, rtol=1e-5, atol=1e-4)
+
+
 def test_beam_scores_vs_oracle():
     d, cfg, _ = load("tiny_l2_attn")
     m, _ = model_for("tiny_l2_attn")
