@@ -206,7 +206,13 @@ int i2l_sample_decode(const i2l_decoder_weights* w, const void* workspace, int r
  * accumulated in fp64, stable descending selection, ended beams retire one iteration
  * later, no length normalisation.  workspace prepared for rows == images.
  *   seq_out  (images, steps+1) int32: best sequence, START stripped, cut at END, -1 padded
- *   len_out  (images) int32;  score_out (images) fp64 or NULL. */
+ *   len_out  (images) int32;  score_out (images) fp64 or NULL.
+ * Kernel choice: hidden == 256, one layer, vocab <= 512, 2 <= beam <= 6 run the grouped kernel (four workgroups
+ * share 12 beam slots = 12/beam images and keep the weights on chip; per step they exchange h and, per slot, each
+ * member's local top-k and (max, sum exp), from which log_softmax is assembled); other shapes, and
+ * I2L_BEAM_GROUP=0 in the environment (read at every call), run one workgroup per image.  Both give the same
+ * sequences; scores agree to fp32 log_softmax rounding.  If a poll of the grouped kernel times out (GPU shared
+ * or oversubscribed) the affected images get len_out = -3 and no other output: call again with I2L_BEAM_GROUP=0. */
 size_t i2l_beam_workspace_bytes(int images, int beam, int hidden, int layers, int steps);
 int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspace, int images, int beam,
                     int steps, int start_id, int end_id, void* beam_workspace,
