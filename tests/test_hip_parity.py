@@ -263,6 +263,26 @@ def test_grouped_beam_matches_workgroup_per_image(k, monkeypatch):
     assert np.allclose(gs, ws, rtol=1e-5, atol=1e-4)
 
 
+def test_grouped_beam_small_vocabulary_and_many_groups(monkeypatch):
+    """Vocabulary 300 (< 512: member 2 of a group owns 44 valid columns, member 3 none, so its candidates are all
+    invalid and its (max, sum exp) is (-inf, 0)); 140 images at k = 5 = 70 groups = 280 workgroups, more than the
+    chip holds at once, so later groups start as earlier ones finish."""
+    cfg = synth.model_config(vocab_size=300, attention=True)
+    m = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+    sd = synth.make_state_dict(cfg, seed=11, out_scale=12.0, enc_scale=16.0, end_clock=(0.05, 12.0, 6.0))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    imgs = torch.from_numpy(synth.make_images(140, cfg, seed=5)).to(DEV)
+    with torch.no_grad():
+        enc = m.encoder(imgs)
+        got, gs = m.beam_search_batch(enc, START, END, 40, 5, return_scores=True)
+        monkeypatch.setenv("I2L_BEAM_GROUP", "0")
+        want, ws = m.beam_search_batch(enc, START, END, 40, 5, return_scores=True)
+    assert got == want
+    assert np.allclose(gs, ws, rtol=1e-5, atol=1e-4)
+    assert max(max(s) for s in got if s) < 300
+
+
 def test_beam_scores_vs_oracle():
     d, cfg, _ = load("tiny_l2_attn")
     m, _ = model_for("tiny_l2_attn")
