@@ -545,27 +545,38 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
             sloc += dpp_f<0x124>(sloc);
             sloc += dpp_f<0x122>(sloc);
             sloc += dpp_f<0x121>(sloc);
-            // K rounds of (largest value, then lowest column holding it): 32-bit maxima / minima over the row
-            float myv = -INFINITY;
+            // K rounds of (largest value, then lowest column holding it) on order-preserving unsigned images of the
+            // values (0 = excluded or already taken): integer maxima / minima over the row, no NaN canonicalisation
+            unsigned o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                unsigned u = __float_as_uint(x[i] + 0.0f);   // -0 -> +0
+                u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+                o[i] = x[i] > -INFINITY ? u : 0u;
+            }
+            unsigned myo = 0;
             int myi = 0xFFFF;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                float bv = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
-                bv = fmaxf(bv, dpp_f<0x128>(bv));
-                bv = fmaxf(bv, dpp_f<0x124>(bv));
-                bv = fmaxf(bv, dpp_f<0x122>(bv));
-                bv = fmaxf(bv, dpp_f<0x121>(bv));
+                unsigned bo = max(max(max(o[0], o[1]), max(o[2], o[3])), max(max(o[4], o[5]), max(o[6], o[7])));
+                bo = max(bo, (unsigned)__builtin_amdgcn_mov_dpp((int)bo, 0x128, 0xF, 0xF, true));
+                bo = max(bo, (unsigned)__builtin_amdgcn_mov_dpp((int)bo, 0x124, 0xF, 0xF, true));
+                bo = max(bo, (unsigned)__builtin_amdgcn_mov_dpp((int)bo, 0x122, 0xF, 0xF, true));
+                bo = max(bo, (unsigned)__builtin_amdgcn_mov_dpp((int)bo, 0x121, 0xF, 0xF, true));
                 int bi = 0xFFFF;                             // local column 16 i + l16
 #pragma unroll
-                for (int i = 7; i >= 0; --i) bi = (x[i] == bv && bv > -INFINITY) ? 16 * i + l16 : bi;
+                for (int i = 7; i >= 0; --i) bi = o[i] == bo ? 16 * i + l16 : bi;
+                bi = bo != 0u ? bi : 0xFFFF;
                 bi = min(bi, __builtin_amdgcn_mov_dpp(bi, 0x128, 0xF, 0xF, true));
                 bi = min(bi, __builtin_amdgcn_mov_dpp(bi, 0x124, 0xF, 0xF, true));
                 bi = min(bi, __builtin_amdgcn_mov_dpp(bi, 0x122, 0xF, 0xF, true));
                 bi = min(bi, __builtin_amdgcn_mov_dpp(bi, 0x121, 0xF, 0xF, true));
-                if (l16 == j) { myv = bv; myi = bi; }
+                if (l16 == j) { myo = bo; myi = bi; }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = (bi == 16 * i + l16) ? -INFINITY : x[i];
+                for (int i = 0; i < 8; ++i) o[i] = (bi == 16 * i + l16) ? 0u : o[i];
             }
+            const unsigned myu = myo ^ ((myo >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+            const float myv = __uint_as_float(myu);
             u64_t out = 0;
             if (l16 < K)
                 out = myi != 0xFFFF ? granule((epoch << 16) | (unsigned)(128 * m + myi), myv)
