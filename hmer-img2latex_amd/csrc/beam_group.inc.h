@@ -138,8 +138,7 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
     const int ul = tid >> 3, ke = tid & 7;
     const int unit = 64 * m + ul;
     const int cq = tid >> 4, ks = tid & 15;
-    const int l_row = ks & 3, l_col = ((ks >> 2) & 1) * 2 + (ks >> 3);
-    const int l_v = 128 * m + 4 * cq + l_col;
+    const int l_v = 128 * m + 4 * cq + ((ks >> 2) & 1) * 2 + (ks >> 3);   // the column whose bias this lane adds in E
 
     f32x2 wreg[32][2];
 #pragma unroll
