@@ -303,14 +303,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
                 const int ci = n / 9, tap = n - 9 * ci, dyy = tap / 3 - 1, dxx = tap - 3 * (tap / 3) - 1;
                 const float* img = g.W + ow + (size_t)ci * g.conv_h * g.conv_w;
                 float v[8];
+                if ((g.conv_w & 7) == 0 && kk + 8 <= kend) {
+                    // the 8 positions share one image row (kk % 8 == 0): one divide, one row test, and away from the
+                    // left / right edge two 16-byte loads (4-byte aligned) instead of eight scalar ones
+                    const int yy = kk / g.conv_w, xx0 = kk - yy * g.conv_w;
+                    const int iy = yy + dyy;
+                    if (iy >= 0 && iy < g.conv_h) {
+                        const float* rowp = img + (size_t)iy * g.conv_w + xx0 + dxx;
+                        if (xx0 + dxx >= 0 && xx0 + dxx + 8 <= g.conv_w) {
+                            __builtin_memcpy(&st.w[0], rowp, 16);
+                            __builtin_memcpy(&st.w[1], rowp + 4, 16);
+                        } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int pos = kk + j, yy = pos / g.conv_w, xx = pos - yy * g.conv_w;
-                    const int iy = yy + dyy, ix = xx + dxx;
-                    v[j] = (pos < kend && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w) ? img[(size_t)iy * g.conv_w + ix] : 0.f;
+                            for (int j = 0; j < 8; ++j) {
+                                const int ix = xx0 + dxx + j;
+                                v[j] = (ix >= 0 && ix < g.conv_w) ? rowp[j] : 0.f;
+                            }
+                            st.w[0] = make_float4(v[0], v[1], v[2], v[3]);
+                            st.w[1] = make_float4(v[4], v[5], v[6], v[7]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int pos = kk + j, yy = pos / g.conv_w, xx = pos - yy * g.conv_w;
+                        const int iy = yy + dyy, ix = xx + dxx;
+                        v[j] = (pos < kend && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w) ? img[(size_t)iy * g.conv_w + ix] : 0.f;
+                    }
+                    st.w[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    st.w[1] = make_float4(v[4], v[5], v[6], v[7]);
                 }
-                st.w[0] = make_float4(v[0], v[1], v[2], v[3]);
-                st.w[1] = make_float4(v[4], v[5], v[6], v[7]);
             }
         } else {
             load8(W_KC, pw + ow, g.ldw, okw, k0 + w_kg * 8, kend, st.w[0], st.w[1]);
