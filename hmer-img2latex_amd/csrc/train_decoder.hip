@@ -465,14 +465,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
     for (; m < m1; ++m) s += A[m * N + n];
     partial[(size_t)blockIdx.y * N + n] = s;
 }
+// 32 columns x 8 row lanes per workgroup: lane r adds the partial rows r, r + 8, ... (four loads in flight), the eight
+// sums meet in LDS and are added in lane order -- a fixed order, so the result is deterministic
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int N,
                                                            float* __restrict__ out, float* __restrict__ out2) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float sm[8][32];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * N + n];
-    out[n] = s;
-    if (out2) out2[n] = s;
+    if (n < N) {
+        int b = r;
+        for (; b + 24 < nblk; b += 32) {
+            const float v0 = partial[(size_t)b * N + n], v1 = partial[(size_t)(b + 8) * N + n];
+            const float v2 = partial[(size_t)(b + 16) * N + n], v3 = partial[(size_t)(b + 24) * N + n];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < nblk; b += 8) s += partial[(size_t)b * N + n];
+    }
+    sm[r][c] = s;
+    __syncthreads();
+    if (r == 0 && n < N) {
+        float t = sm[0][c];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += sm[i][c];
+        out[n] = t;
+        if (out2) out2[n] = t;
+    }
 }
 
 // dEmb[tok[bt]] += dX[bt][:E] * mask ;  dEnc[b] = sum_t dX[b,t][E:] * mask
@@ -609,7 +627,7 @@ int colsum(const float* A, size_t M, int N, float* partial, float* out, float* o
     nblk = (int)((M + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum_kernel, dim3(i2l_cdiv(N, 256), nblk), dim3(256), 0, s, A, M, N, rpb, partial);
     I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(i2l_cdiv(N, 256)), dim3(256), 0, s, partial, nblk, N, out, out2);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(i2l_cdiv(N, 32)), dim3(256), 0, s, partial, nblk, N, out, out2);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }
