@@ -504,7 +504,8 @@ __global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restric
         const int e = (int)(i - bt * E);
         const int tk = min(max(tok[bt], 0), V - 1);
         const float k = keep_scale(seed, DS_X, attn_path ? bt * E + e : bt * 2 * E + e, p, inv_keep);
-        atomicAdd(dEmb + (size_t)tk * E + e, dX[bt * 2 * E + e] * k);
+        const float v = dX[bt * 2 * E + e] * k;
+        if (v != 0.f) atomicAdd(dEmb + (size_t)tk * E + e, v);   // rows after a sequence's end carry exact zeros (and hit ONE row: PAD)
     }
 }
 __global__ __launch_bounds__(256) void denc_reduce_kernel(const float* __restrict__ dX, float* __restrict__ dEnc, int B,
