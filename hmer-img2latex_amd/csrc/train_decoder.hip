@@ -508,20 +508,32 @@ __global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restric
         if (v != 0.f) atomicAdd(dEmb + (size_t)tk * E + e, v);   // rows after a sequence's end carry exact zeros (and hit ONE row: PAD)
     }
 }
+// 32 (b, e) outputs x 8 time lanes per workgroup: lane r adds the steps r, r + 8, ..., the eight sums are added in
+// lane order (fixed order: deterministic)
 __global__ __launch_bounds__(256) void denc_reduce_kernel(const float* __restrict__ dX, float* __restrict__ dEnc, int B,
                                                           int T, int E, float p, unsigned long long seed,
                                                           int attn_path) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * E) return;
-    const int b = idx / E, e = idx - b * E;
+    __shared__ float sm[8][32];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + c;
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     float s = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const size_t bt = (size_t)b * T + t;
-        const size_t i = bt * 2 * E + E + e;
-        s += dX[i] * (attn_path ? 1.f : keep_scale(seed, DS_X, i, p, inv_keep));
+    if (idx < B * E) {
+        const int b = idx / E, e = idx - b * E;
+        for (int t = r; t < T; t += 8) {
+            const size_t bt = (size_t)b * T + t;
+            const size_t i = bt * 2 * E + E + e;
+            s += dX[i] * (attn_path ? 1.f : keep_scale(seed, DS_X, i, p, inv_keep));
+        }
     }
-    dEnc[idx] = s;
+    sm[r][c] = s;
+    __syncthreads();
+    if (r == 0 && idx < B * E) {
+        float t = sm[0][c];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += sm[i][c];
+        dEnc[idx] = t;
+    }
 }
 
 __global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
@@ -903,7 +915,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     hipLaunchKernelGGL(emb_scatter_kernel, dim3(grid_for(BT * E)), dim3(256), 0, s, (const float*)F(lo.dX), tokens,
                        gr->embedding, BT, E, V, dropout_p, (unsigned long long)seed, attention_path);
     I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(denc_reduce_kernel, dim3(i2l_cdiv(B * E, 256)), dim3(256), 0, s, (const float*)F(lo.dX),
+    hipLaunchKernelGGL(denc_reduce_kernel, dim3(i2l_cdiv(B * E, 32)), dim3(256), 0, s, (const float*)F(lo.dX),
                        denc_out, B, T, E, dropout_p, (unsigned long long)seed, attention_path);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
