@@ -178,6 +178,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const fl
     }
 }
 
+// Few outputs, many slabs (the conv weight gradients: 864 .. 73,728 outputs, hundreds of slabs): 8 lanes per output
+// add the slabs r, r + 8, ... and their sums meet in lane order (fixed order: deterministic); one thread per output
+// would walk the slabs alone on a handful of CUs.
+__global__ __launch_bounds__(256) void splitk_reduce_lanes_kernel(GemmArgs g, const float* __restrict__ partial,
+                                                                  int slabs) {
+    __shared__ float sm[8][32];
+    const size_t total = (size_t)g.M * g.N, stride = slab_stride(g.M, g.N);
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + c;
+    float v = 0.f;
+    if (i < total) {
+        int s = r;
+        for (; s + 24 < slabs; s += 32) {
+            const float t0 = partial[(size_t)s * stride + i], t1 = partial[(size_t)(s + 8) * stride + i];
+            const float t2 = partial[(size_t)(s + 16) * stride + i], t3 = partial[(size_t)(s + 24) * stride + i];
+            v += t0; v += t1; v += t2; v += t3;
+        }
+        for (; s < slabs; s += 8) v += partial[(size_t)s * stride + i];
+    }
+    sm[r][c] = v;
+    __syncthreads();
+    if (r == 0 && i < total) {
+        float t = sm[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sm[k][c];
+        epilogue_store(g, (int)(i / g.N), (int)(i % g.N), t);
+    }
+}
+void launch_splitk_reduce(const GemmArgs& g, const float* ws, int slabs, hipStream_t s) {
+    const size_t total = (size_t)g.M * g.N;
+    if (g.conv_h > 0 && total <= 131072 && slabs >= 32) {   // the conv weight gradients only: other sums keep their order
+        hipLaunchKernelGGL(splitk_reduce_lanes_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, g, ws, slabs);
+        return;
+    }
+    int rb = (int)((total + 255) / 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, g, ws, slabs);
+}
+
 void plan(int M, int N, int K, int nz, int* ksplits, int* k_chunk) {
     const int tiles = i2l_cdiv(M, BM) * i2l_cdiv(N, BN) * nz;
     int s = 1;
@@ -445,10 +484,7 @@ int run_bf16x3(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
     I2L_CHECK_LAUNCH();
     if (S > 1) {
-        const size_t total = (size_t)g.M * g.N;
-        int rb = (int)((total + 255) / 256);
-        if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, g, (const float*)ws, S);
+        launch_splitk_reduce(g, (const float*)ws, S, s);
         I2L_CHECK_LAUNCH();
     }
     return I2L_OK;
@@ -497,10 +533,7 @@ int i2l_gemm(const GemmArgs& g0, void* ws, size_t ws_bytes, hipStream_t stream) 
     else launch<false, false>(g, wsf, kc, ks, slabs, vec, grid, stream);
     I2L_CHECK_LAUNCH();
     if (slabs > 1) {
-        const size_t total = (size_t)g.M * g.N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g, (const float*)ws, slabs);
+        launch_splitk_reduce(g, (const float*)ws, slabs, stream);
         I2L_CHECK_LAUNCH();
     }
     return I2L_OK;
@@ -535,11 +568,20 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ A, int M, int N,
                                                            float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float sm[8][32];                             // 32 columns x 8 row lanes, lane sums added in lane order
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += A[(size_t)m * N + n];
-    out[n] = s;
+    if (n < N)
+        for (int m = r; m < M; m += 8) s += A[(size_t)m * N + n];
+    sm[r][c] = s;
+    __syncthreads();
+    if (r == 0 && n < N) {
+        float t = sm[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sm[k][c];
+        out[n] = t;
+    }
 }
 size_t lin_bwd_gemm_ws(int M, int K, int N) {
     const size_t a = i2l_gemm_workspace_bytes(N, K, M), b = i2l_gemm_workspace_bytes(M, K, N);
@@ -570,7 +612,7 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
         I2L_CHECK_LAUNCH();
         d = dpre;
     }
-    hipLaunchKernelGGL(colsum_small_kernel, dim3(i2l_cdiv(N, 256)), dim3(256), 0, s, d, M, N, db);
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(i2l_cdiv(N, 32)), dim3(256), 0, s, d, M, N, db);
     I2L_CHECK_LAUNCH();
     {   // dw[n][k] = sum_m d[m][n] * x[m][k]
         GemmArgs g = gemm_args();
