@@ -417,6 +417,12 @@ namespace {
 int run_conv(bool pool, const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B,
              int Cin, int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const int Hp = H / 2, Wp = W / 2;
+    // data gradient on the split-bf16 matrix-core kernel (fp32-grade, like the weight-gradient GEMMs) where the
+    // channel counts and even H, W allow
+    if (!pool && !bias && !amax && ((H | W) & 1) == 0 && i2l_conv_bf16x3_applicable(Cin, Cout)) {
+        if (!workspace || workspace_bytes < i2l_conv_workspace_bytes(Cin, Cout)) return I2L_ERR_WORKSPACE;
+        return i2l_conv_bf16x3_run(x, w, nullptr, y, nullptr, B, Cin, H, W, Cout, workspace, workspace_bytes, s, 1);
+    }
     if (Cout % 32 == 0) {
         const size_t need = i2l_conv_workspace_bytes(Cin, Cout);
         if (!workspace || workspace_bytes < need) return I2L_ERR_WORKSPACE;

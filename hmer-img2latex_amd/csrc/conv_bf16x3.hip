@@ -70,8 +70,9 @@ template <int WX> struct Tile3 {
 };
 
 // wpack3[cb][chunk][tap][split][lh][co 64][8] = split_s( w[cb*64+co][chunk*16 + 8*lh + j][tap] )
+// flip != 0: filter of the DATA-GRADIENT convolution, element = w[ci][co][2-ky][2-kx] of the forward filter w
 __global__ void conv_pack3_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cin, int Cout, int n_chunks,
-                                  size_t total) {
+                                  size_t total, int flip) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (.., co, j) of split 0
     if (idx >= total) return;
     size_t r = idx;
@@ -82,7 +83,7 @@ __global__ void conv_pack3_kernel(const float* __restrict__ w, bf16_t* __restric
     const int chunk = (int)(r % n_chunks);
     const int cb = (int)(r / n_chunks);
     const int co = cb * CO_BLK + co_l, ci = chunk * CH + 8 * lh + j;
-    const float v = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+    const float v = (co < Cout && ci < Cin) ? (flip ? w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : w[((size_t)co * Cin + ci) * 9 + tap]) : 0.f;
     bf16_t s[3];
     split3(v, s[0], s[1], s[2]);
     const size_t slab = ((size_t)cb * n_chunks + chunk) * (size_t)W_SLAB_U4 * 8;
@@ -91,7 +92,8 @@ __global__ void conv_pack3_kernel(const float* __restrict__ w, bf16_t* __restric
         wp[slab + ((((size_t)tap * 3 + sp) * 2 + lh) * CO_BLK + co_l) * 8 + j] = s[sp];
 }
 
-template <int WX>
+// FULL: plain full-resolution convolution (no bias / ReLU / pooling): the data gradient of a block, y is (B,Cout,H,W)
+template <int WX, bool FULL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wpack, const float* __restrict__ bias,
     float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
@@ -251,6 +253,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 
         // ---- epilogue (same lane layout as conv.hip): registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h
         const int py0 = y0 >> 1, px0 = x0 >> 1;
+        if constexpr (FULL) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int co = cb * CO_BLK + n * 32 + i;
+                if (co >= Cout) continue;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int py = py0 + wy * 2 + m;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int px = px0 + wx * 8 + 2 * q + h;
+#pragma unroll
+                        for (int ry = 0; ry < 2; ++ry) {             // quad element e = 2 ry + rx: two adjacent columns
+                            const int Y = 2 * py + ry, X = 2 * px;
+                            if (Y < H && X + 1 < W)
+                                *reinterpret_cast<float2*>(y + (((size_t)b * Cout + co) * H + Y) * W + X) =
+                                    make_float2(acc[m][n][4 * q + 2 * ry], acc[m][n][4 * q + 2 * ry + 1]);
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         if (amax == nullptr && (Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
             // out_s was last read before the first barrier of this tile's first phase: free to overwrite
 #pragma unroll
@@ -464,14 +489,15 @@ size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout) {
 }
 
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
-                        int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                        int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, int full) {
+    if (full && ((H | W) & 1)) return I2L_ERR_UNSUPPORTED;       // full resolution is written quad by quad
     if (workspace_bytes < i2l_conv_bf16x3_workspace_bytes(Cin, Cout) || !workspace) return I2L_ERR_WORKSPACE;
     const int Hp = H / 2, Wp = W / 2;
     const int n_chunks = Cin / CH, co_blocks = Cout / CO_BLK;
     bf16_t* wp = static_cast<bf16_t*>(workspace);
     const size_t total = (size_t)co_blocks * n_chunks * 9 * 2 * CO_BLK * 8;
     hipLaunchKernelGGL(conv_pack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout,
-                       n_chunks, total);
+                       n_chunks, total, full ? 1 : 0);
     I2L_CHECK_LAUNCH();
     const int rows = 2 * Hp, cols = 2 * Wp;
     // tile shape with the fewest wasted positions (8x32, 16x16 or 4x64; ties: 8x32)
@@ -495,8 +521,14 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     while (i2l_cdiv(n_items, items_per_wg) > 65535) ++items_per_wg;
     dim3 grid(co_blocks, i2l_cdiv(n_items, items_per_wg));
 #define I2L_LAUNCH3(WXV)                                                                                              \
-    hipLaunchKernelGGL(conv3x3_bf16x3_kernel<WXV>, grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, amax, Cin, H, W, \
-                       Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg)
+    do {                                                                                                              \
+        if (full)                                                                                                     \
+            hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, true>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y,  \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, false>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+    } while (0)
     if (wx == 2) I2L_LAUNCH3(2);
     else if (wx == 1) I2L_LAUNCH3(1);
     else I2L_LAUNCH3(4);
