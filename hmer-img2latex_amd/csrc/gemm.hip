@@ -252,7 +252,7 @@ void launch(const GemmArgs& g, float* ws, int kc, int ks, int slabs, bool vec, d
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
 typedef float f32v2_t __attribute__((ext_vector_type(2)));
-constexpr int LBM = 128, LBN = 64, LBK = 32, LPA = LBM + 2, LPW = LBN + 2;
+constexpr int LBN = 64, LBK = 32, LPW = LBN + 2;
 
 __device__ __forceinline__ void lsplit3_pair(float x0, float x1, unsigned& s0, unsigned& s1, unsigned& s2) {
     f32v2_t v = {x0, x1};
@@ -276,10 +276,11 @@ __device__ __forceinline__ void lsplit_piece(const float4& lo, const float4& hi,
     for (int sp = 0; sp < 3; ++sp) out[sp] = make_uint4(p[sp][0], p[sp][1], p[sp][2], p[sp][3]);
 }
 
-template <bool A_KC, bool W_KC>
+template <bool A_KC, bool W_KC, int MT>      // MT = 32-row MFMA tiles per wave: workgroup tile (64 MT) x 64
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* __restrict__ partial, int k_chunk,
                                                              int S, int tiles_n, int tiles) {
-    __shared__ __attribute__((aligned(16))) uint4 a_s[3 * 4 * LPA];
+    constexpr int LBM_ = 64 * MT, LPA_ = LBM_ + 2;
+    __shared__ __attribute__((aligned(16))) uint4 a_s[3 * 4 * LPA_];
     __shared__ __attribute__((aligned(16))) uint4 w_s[3 * 4 * LPW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
     if ((S & 7) == 0) { const int grp = L >> 3; tile = grp % tiles; slice = (L & 7) + 8 * (grp / tiles); }
     else { tile = L % tiles; slice = L / tiles; }
     if (slice >= S) return;
-    const int m0 = (tile / tiles_n) * LBM, n0 = (tile % tiles_n) * LBN;
+    const int m0 = (tile / tiles_n) * LBM_, n0 = (tile % tiles_n) * LBN;
     // the reduction runs over the flattened (operand pair z, k) range; K % 32 == 0 when nz > 1, so a chunk never
     // straddles two pairs
     const long kf_beg = (long)slice * k_chunk, kf_end = min((long)g.nz * g.K, kf_beg + k_chunk);
@@ -299,10 +300,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
     // staging: piece = (row, k group kg of 8); A: 2 pieces per thread, W: 1.  K-contiguous operands: 4 lanes cover the
     // 4 k groups of one row (two float4 loads each); M/N-contiguous operands: consecutive lanes = consecutive rows
     // (8 strided 4-byte loads each, coalesced across lanes).  Either way a piece lands at (split, kg) plane + row.
-    const int a_row0 = A_KC ? (tid >> 2) : (tid & 127), a_kg0 = A_KC ? (tid & 3) : (tid >> 7);
+    const int a_row0 = A_KC ? (tid >> 2) : (MT == 2 ? (tid & 127) : (tid & 63)), a_kg0 = A_KC ? (tid & 3) : (MT == 2 ? (tid >> 7) : (tid >> 6));
     const int a_row1 = A_KC ? 64 + (tid >> 2) : (tid & 127), a_kg1 = A_KC ? (tid & 3) : 2 + (tid >> 7);
     const int w_row = W_KC ? (tid >> 2) : (tid & 63), w_kg = W_KC ? (tid & 3) : (tid >> 6);
-    const bool oka0 = m0 + a_row0 < g.M, oka1 = m0 + a_row1 < g.M, okw = n0 + w_row < g.N;
+    const bool oka0 = m0 + a_row0 < g.M, oka1 = MT == 2 && m0 + a_row1 < g.M, okw = n0 + w_row < g.N;
     const float* pa0 = A_KC ? g.A + (size_t)min(m0 + a_row0, g.M - 1) * g.lda : g.A + min(m0 + a_row0, g.M - 1);
     const float* pa1 = A_KC ? g.A + (size_t)min(m0 + a_row1, g.M - 1) * g.lda : g.A + min(m0 + a_row1, g.M - 1);
     const float* pw = W_KC ? g.W + (size_t)min(n0 + w_row, g.N - 1) * g.ldw : g.W + min(n0 + w_row, g.N - 1);
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         const int kend = (int)min((long)g.K, kf_end - (long)z * g.K);
         const size_t oa = (size_t)z * g.bsa, ow = (size_t)z * g.bsw;
         load8(A_KC, pa0 + oa, g.lda, oka0, k0 + a_kg0 * 8, kend, st.a[0][0], st.a[0][1]);
-        load8(A_KC, pa1 + oa, g.lda, oka1, k0 + a_kg1 * 8, kend, st.a[1][0], st.a[1][1]);
+        if (MT == 2) load8(A_KC, pa1 + oa, g.lda, oka1, k0 + a_kg1 * 8, kend, st.a[1][0], st.a[1][1]);
         if (g.conv_h > 0) {
             // implicit im2col^T: row n = n0 + w_row = (ci, tap), 8 consecutive positions k of image z
             const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -381,18 +382,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         uint4 o[3];
         lsplit_piece(st.a[0][0], st.a[0][1], o);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + a_kg0) * LPA + a_row0] = o[sp];
-        lsplit_piece(st.a[1][0], st.a[1][1], o);
+        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + a_kg0) * LPA_ + a_row0] = o[sp];
+        if (MT == 2) {
+            lsplit_piece(st.a[1][0], st.a[1][1], o);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + a_kg1) * LPA + a_row1] = o[sp];
+            for (int sp = 0; sp < 3; ++sp) a_s[(sp * 4 + a_kg1) * LPA_ + a_row1] = o[sp];
+        }
         lsplit_piece(st.w[0], st.w[1], o);
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) w_s[(sp * 4 + w_kg) * LPW + w_row] = o[sp];
     };
 
-    f32x16 acc[2];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
@@ -402,13 +405,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         if (k0 + 2 * LBK < kf_end) fetch(nxt2, k0 + 2 * LBK);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8_t a[2][3], b[3];
+            bf16x8_t a[MT][3], b[3];
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) {
                 const int plane = sp * 4 + s * 2 + h;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const uint4 t = a_s[plane * LPA + wm * 64 + m * 32 + i];
+                for (int m = 0; m < MT; ++m) {
+                    const uint4 t = a_s[plane * LPA_ + wm * 32 * MT + m * 32 + i];
                     a[m][sp] = *reinterpret_cast<const bf16x8_t*>(&t);
                 }
                 const uint4 t = w_s[plane * LPW + wn * 32 + i];
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MT; ++m)
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][TI[t]], b[TJ[t]], acc[m], 0, 0, 0);
         }
         __syncthreads();
@@ -432,10 +435,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
     }
     const int n = n0 + wn * 32 + i;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = m0 + wm * 32 * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < g.M && n < g.N) {
                 if (S > 1) partial[(size_t)slice * slab_stride(g.M, g.N) + (size_t)row * g.N + n] = acc[m][r];
                 else epilogue_store(g, row, n, acc[m][r]);
@@ -443,8 +446,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         }
 }
 
+// 64-row workgroup tiles for M <= 64 (the weight gradients of the first two conv blocks, the FC layer of a 64-image
+// shard): half of a 128-row tile would be padding
+int bf16x3_mt(int M) { return M <= 64 ? 1 : 2; }
+
 void plan_bf16x3(int M, int N, long KT, int* S, int* k_chunk) {      // KT = nz * K, the flattened reduction length
-    const int tiles = i2l_cdiv(M, LBM) * i2l_cdiv(N, LBN);
+    const int tiles = i2l_cdiv(M, 64 * bf16x3_mt(M)) * i2l_cdiv(N, LBN);
     long s = 512 / tiles;
     const long max_s = KT / 256;              // keep >= 256 of the reduction per slice
     if (s > max_s) s = max_s;
@@ -473,15 +480,22 @@ int run_bf16x3(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s) {
     int S, kc;
     plan_bf16x3(g.M, g.N, (long)g.nz * g.K, &S, &kc);
     if (S > 1 && (!ws || ws_bytes < (size_t)S * slab_stride(g.M, g.N) * sizeof(float))) return I2L_ERR_WORKSPACE;
-    const int tiles_n = i2l_cdiv(g.N, LBN), tiles = i2l_cdiv(g.M, LBM) * tiles_n;
+    const int mt = bf16x3_mt(g.M);
+    const int tiles_n = i2l_cdiv(g.N, LBN), tiles = i2l_cdiv(g.M, 64 * mt) * tiles_n;
     const long long blocks = (long long)tiles * S;
     if (blocks > 0x7fffffffll) return I2L_ERR_UNSUPPORTED;
     dim3 grid((unsigned)blocks);
     float* wsf = static_cast<float*>(ws);
-    if (g.a_kc && g.w_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
-    else if (g.a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
-    else if (g.w_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);
+#define I2L_LAUNCH_BF16X3(AK, WK)                                                                                          \
+    do {                                                                                                                \
+        if (mt == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 2>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles); \
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 1>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);  \
+    } while (0)
+    if (g.a_kc && g.w_kc) I2L_LAUNCH_BF16X3(true, true);
+    else if (g.a_kc) I2L_LAUNCH_BF16X3(true, false);
+    else if (g.w_kc) I2L_LAUNCH_BF16X3(false, true);
+    else I2L_LAUNCH_BF16X3(false, false);
+#undef I2L_LAUNCH_BF16X3
     I2L_CHECK_LAUNCH();
     if (S > 1) {
         launch_splitk_reduce(g, (const float*)ws, S, s);
