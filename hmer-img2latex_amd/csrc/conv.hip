@@ -543,14 +543,16 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__
 }
 
 // db[c] = sum_{b,pos} dyp[b][c][pos]: grid (C, B) partial sums per image, then an ordered sum over images
-// (deterministic).
-__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ dyp, double* __restrict__ partial,
-                                                        int B, int C, size_t HW) {
+// (deterministic), taken from the POOLED tensors: the un-pooled gradient holds, per 2x2 window, dy where y > 0 and zeros
+// elsewhere, so db[c] = sum over pooled positions of (y > 0 ? dy : 0) -- a quarter of the bytes
+__global__ __launch_bounds__(256) void plane_sum_pooled_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               double* __restrict__ partial, int B, int C, size_t HWp) {
     __shared__ double red[256];
     const int c = blockIdx.x, b = blockIdx.y;
-    const float* p = dyp + ((size_t)b * C + c) * HW;
+    const float* pd = dy + ((size_t)b * C + c) * HWp;
+    const float* py = y + ((size_t)b * C + c) * HWp;
     double s = 0.0;
-    for (size_t i = threadIdx.x; i < HW; i += 256) s += p[i];
+    for (size_t i = threadIdx.x; i < HWp; i += 256) s += py[i] > 0.f ? pd[i] : 0.f;
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -629,7 +631,7 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     }
     if (B > 65535) return I2L_ERR_UNSUPPORTED;
     double* psum = reinterpret_cast<double*>(base + lo.psum);
-    hipLaunchKernelGGL(plane_sum_kernel, dim3(Cout, B), dim3(256), 0, s, (const float*)dyp, psum, B, Cout, HW);
+    hipLaunchKernelGGL(plane_sum_pooled_kernel, dim3(Cout, B), dim3(256), 0, s, dy, y, psum, B, Cout, (size_t)Hp * Wp);
     I2L_CHECK_LAUNCH();
     hipLaunchKernelGGL(plane_sum_final_kernel, dim3(i2l_cdiv(Cout, 64)), dim3(64), 0, s, (const double*)psum, db, B, Cout);
     I2L_CHECK_LAUNCH();
