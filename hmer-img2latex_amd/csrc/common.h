@@ -33,6 +33,11 @@ struct GemmArgs {
     int split_bf16;           // allow the split-bf16 matrix-core kernel (fp32-grade, not an fmaf chain); gemm.hip
     int conv_h, conv_w;       // > 0 (split-bf16 kernel only): W is an implicit im2col^T of a (Cin, conv_h, conv_w) image per
                               // operand pair: W(n = ci*9 + tap, k = y*conv_w + x) = img[ci][y + tap/3 - 1][x + tap%3 - 1], 0 outside
+    // with conv_h > 0 and pool_y != null: A is NOT the un-pooled gradient but the POOLED one, (M, conv_h/2, conv_w/2) per
+    // operand pair (lda = bsa / M = pooled plane size), and is un-pooled on the fly:
+    //   A(m, k = y*conv_w + x) = (pool_y > 0 && pool_am == 2*(y&1) + (x&1)) ? A_pooled[m][y/2][x/2] : 0      (conv_w % 8 == 0)
+    const float* pool_y;
+    const unsigned char* pool_am;
 };
 static inline GemmArgs gemm_args() {
     GemmArgs g{};

@@ -614,7 +614,19 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     hipStream_t s = i2l_s(stream);
     const int Hp = H / 2, Wp = W / 2;
     const size_t HW = (size_t)H * W;
-    {
+    // Block 0 needs no data gradient (dx == null): its weight-gradient GEMM un-pools dy on the fly (GemmArgs::pool_y),
+    // so the un-pooled gradient -- 168 MB at 64 x 32 x 64 x 320 -- is never written
+    GemmArgs gp = gemm_args();
+    gp.A = dy; gp.lda = (long)Hp * Wp; gp.bsa = (long)Cout * Hp * Wp;
+    gp.pool_y = y; gp.pool_am = argmax;
+    gp.W = x; gp.ldw = (long)HW; gp.bsw = (long)(Cin * HW);
+    gp.conv_h = H; gp.conv_w = W;
+    gp.nz = B;
+    gp.split_bf16 = 1;
+    gp.C = dw; gp.ldc = Cin * 9;
+    gp.M = Cout; gp.N = Cin * 9; gp.K = (int)HW;
+    const bool fused_unpool = !dx && (H % 2) == 0 && (W % 2) == 0 && i2l_gemm_split_bf16_ok(gp);
+    if (!fused_unpool) {
         const size_t total = (size_t)B * Cout * HW;
         size_t blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
@@ -637,7 +649,12 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     I2L_CHECK_LAUNCH();
     // weight gradient: dw[co][(ci,tap)] = sum_b sum_pos dyp[b][co][pos] * colT[b][(ci,tap)][pos]
     bool wgrad_done = false;
-    {   // one GEMM over the whole batch, the im2col^T operand gathered inside the kernel (no colT image)
+    if (fused_unpool) {
+        const int rc = i2l_gemm(gp, base + lo.gemm, lo.gemm_bytes, s);
+        if (rc != I2L_OK) return rc;
+        wgrad_done = true;
+    }
+    if (!wgrad_done) {   // one GEMM over the whole batch, the im2col^T operand gathered inside the kernel (no colT image)
         GemmArgs g = gemm_args();
         g.A = dyp; g.lda = (long)HW; g.bsa = (long)(Cout * HW);
         g.W = x; g.ldw = (long)HW; g.bsw = (long)(Cin * HW);

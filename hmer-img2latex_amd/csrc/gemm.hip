@@ -332,8 +332,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* 
         const int z = (int)(kf0 / g.K), k0 = (int)(kf0 - (long)z * g.K);
         const int kend = (int)min((long)g.K, kf_end - (long)z * g.K);
         const size_t oa = (size_t)z * g.bsa, ow = (size_t)z * g.bsw;
+        if (A_KC && g.pool_y) {
+            // un-pool on the fly: 8 consecutive positions of one image row <- 4 pooled windows (dy, y, arg max)
+            auto unpool8 = [&](int row, bool ok, int k, float4& lo, float4& hi) {
+                const float4 zz4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                lo = zz4; hi = zz4;
+                if (!ok || k >= kend) return;
+                const int yy = k / g.conv_w, xx0 = k - yy * g.conv_w;
+                const size_t o = (size_t)z * g.bsa + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)(yy >> 1) * (g.conv_w >> 1) + (xx0 >> 1);
+                const float4 d4 = *reinterpret_cast<const float4*>(g.A + o);
+                const float4 y4 = *reinterpret_cast<const float4*>(g.pool_y + o);
+                const unsigned a4 = *reinterpret_cast<const unsigned*>(g.pool_am + o);
+                const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pc = j >> 1;
+                    const unsigned am = (a4 >> (8 * pc)) & 0xFFu;
+                    v[j] = (yv[pc] > 0.f && am == (unsigned)(2 * (yy & 1) + (j & 1))) ? dv[pc] : 0.f;
+                }
+                lo = make_float4(v[0], v[1], v[2], v[3]);
+                hi = make_float4(v[4], v[5], v[6], v[7]);
+            };
+            unpool8(a_row0, oka0, k0 + a_kg0 * 8, st.a[0][0], st.a[0][1]);
+            if (MT == 2) unpool8(a_row1, oka1, k0 + a_kg1 * 8, st.a[1][0], st.a[1][1]);
+        } else {
         load8(A_KC, pa0 + oa, g.lda, oka0, k0 + a_kg0 * 8, kend, st.a[0][0], st.a[0][1]);
         if (MT == 2) load8(A_KC, pa1 + oa, g.lda, oka1, k0 + a_kg1 * 8, kend, st.a[1][0], st.a[1][1]);
+        }
         if (g.conv_h > 0) {
             // implicit im2col^T: row n = n0 + w_row = (ci, tap), 8 consecutive positions k of image z
             const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -470,7 +496,11 @@ bool split_bf16_exact_mode() {
 bool bf16x3_applicable(const GemmArgs& g) {
     if (split_bf16_exact_mode() || g.K < 64 || (g.nz > 1 && (g.K % LBK != 0 || (long)g.nz * g.K > 0x7fffffffl))) return false;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    if (g.a_kc && (!al16(g.A) || g.lda % 4 != 0 || g.K % 8 != 0)) return false;
+    if (g.pool_y) {
+        if (!(g.conv_h > 0 && g.a_kc && g.pool_am && (g.conv_w % 8) == 0 && (g.conv_h % 2) == 0 && al16(g.A) && al16(g.pool_y) &&
+              reinterpret_cast<uintptr_t>(g.pool_am) % 4 == 0 && g.lda % 4 == 0 && g.bsa % 4 == 0))
+            return false;
+    } else if (g.a_kc && (!al16(g.A) || g.lda % 4 != 0 || g.K % 8 != 0)) return false;
     if (g.conv_h > 0) return g.w_kc && g.K == g.conv_h * g.conv_w;     // gathered W: no alignment requirement
     if (g.w_kc && (!al16(g.W) || g.ldw % 4 != 0 || g.K % 8 != 0)) return false;
     return true;
