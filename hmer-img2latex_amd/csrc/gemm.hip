@@ -277,7 +277,7 @@ __device__ __forceinline__ void lsplit_piece(const float4& lo, const float4& hi,
 }
 
 template <bool A_KC, bool W_KC, int MT>      // MT = 32-row MFMA tiles per wave: workgroup tile (64 MT) x 64
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g, float* __restrict__ partial, int k_chunk,
+__global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(GemmArgs g, float* __restrict__ partial, int k_chunk,
                                                              int S, int tiles_n, int tiles) {
     constexpr int LBM_ = 64 * MT, LPA_ = LBM_ + 2;
     __shared__ __attribute__((aligned(16))) uint4 a_s[3 * 4 * LPA_];
