@@ -478,7 +478,9 @@ int bf16x3_mt(int M) { return M <= 64 ? 1 : 2; }
 
 void plan_bf16x3(int M, int N, long KT, int* S, int* k_chunk) {      // KT = nz * K, the flattened reduction length
     const int tiles = i2l_cdiv(M, 64 * bf16x3_mt(M)) * i2l_cdiv(N, LBN);
-    long s = 512 / tiles;
+    // three workgroups per CU are resident (768 slots); outputs of 64 K elements and more pay too much for the extra
+    // slabs (the encoder's FC layer: 55 -> 58 us at 96 slabs), they keep the 512-slot split
+    long s = ((long)M * N >= 65536 ? 512 : 768) / tiles;
     const long max_s = KT / 256;              // keep >= 256 of the reduction per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
