@@ -143,7 +143,7 @@ class Seq2SeqModel(nn.Module):
                        "beam_decode")
         launch()
         seq_h, ln_h = seq.cpu(), ln.cpu()
-        if int(ln_h.min()) <= -3:
+        if min(ln_h.tolist()) <= -3:
             # the grouped kernel needs its four workgroups resident together; on a GPU shared with other work a
             # poll can time out (len -3): run the one-workgroup-per-image kernel instead
             warnings.warn("img2latex_amd: grouped beam search timed out, re-running with one workgroup per image")
@@ -158,7 +158,8 @@ class Seq2SeqModel(nn.Module):
                     os.environ["I2L_BEAM_GROUP"] = prev
             seq_h, ln_h = seq.cpu(), ln.cpu()
         del keep
-        out = [seq_h[j, : int(ln_h[j])].tolist() for j in range(n)]
+        lens = ln_h.tolist()                                   # one conversion each, then plain list slices
+        out = [row[:ln_j] for row, ln_j in zip(seq_h.tolist(), lens)]
         if return_scores:
             return out, score.cpu().tolist()
         return out
