@@ -49,7 +49,7 @@ int i2l_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s);
 bool i2l_gemm_split_bf16_ok(const GemmArgs& g);   // would i2l_gemm run this on the split-bf16 kernel?
 
 // ---- 3 x bf16 split conv block on the bf16 matrix cores (conv_bf16x3.hip); inference forward of blocks with
-//      Cin % 16 == 0 and Cout % 64 == 0 unless I2L_CONV_EXACT_FP32=1
+//      Cin % 16 == 0 and Cout % 64 == 0 (shape test only: the caller decides on I2L_FLAG_EXACT_FP32)
 bool i2l_conv_bf16x3_applicable(int Cin, int Cout);
 size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout);
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,

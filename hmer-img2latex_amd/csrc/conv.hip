@@ -396,7 +396,7 @@ int launch_mfma(bool pool, int co_blocks, int B, hipStream_t s, const float* x, 
 // One 3x3 / pad 1 convolution launch.  pool: fused bias+ReLU+maxpool2 (+argmax); !pool: plain full-resolution
 // conv with the flipped/transposed filter (data gradient).  `wpack_ws` must hold i2l_conv_workspace_bytes().
 int run_conv(bool pool, const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B,
-             int Cin, int H, int W, int Cout, void* wpack_ws, size_t ws_bytes, hipStream_t s);
+             int Cin, int H, int W, int Cout, void* wpack_ws, size_t ws_bytes, hipStream_t s, bool exact);
 
 }  // namespace
 
@@ -415,11 +415,11 @@ extern "C" size_t i2l_conv_workspace_bytes(int Cin, int Cout) {
 namespace {
 
 int run_conv(bool pool, const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B,
-             int Cin, int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s) {
+             int Cin, int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, bool exact) {
     const int Hp = H / 2, Wp = W / 2;
     // data gradient on the split-bf16 matrix-core kernel (fp32-grade, like the weight-gradient GEMMs) where the
     // channel counts and even H, W allow
-    if (!pool && !bias && !amax && ((H | W) & 1) == 0 && i2l_conv_bf16x3_applicable(Cin, Cout)) {
+    if (!exact && !pool && !bias && !amax && ((H | W) & 1) == 0 && i2l_conv_bf16x3_applicable(Cin, Cout)) {
         if (!workspace || workspace_bytes < i2l_conv_workspace_bytes(Cin, Cout)) return I2L_ERR_WORKSPACE;
         return i2l_conv_bf16x3_run(x, w, nullptr, y, nullptr, B, Cin, H, W, Cout, workspace, workspace_bytes, s, 1);
     }
@@ -462,14 +462,16 @@ int run_conv(bool pool, const float* x, const float* w, const float* bias, float
 
 extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias, float* y,
                                            unsigned char* argmax_out, int B, int Cin, int H, int W, int Cout,
-                                           void* workspace, size_t workspace_bytes, i2l_stream_t stream) {
+                                           void* workspace, size_t workspace_bytes, int flags,
+                                           i2l_stream_t stream) {
     if (!x || !w || !bias || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2) return I2L_ERR_ARG;
+    const bool exact = (flags & I2L_FLAG_EXACT_FP32) != 0;
     // inference forward (no argmax wanted): split-bf16 matrix-core kernel where the channel counts allow
-    if (!argmax_out && i2l_conv_smallk_applicable(Cin, Cout))
+    if (!exact && !argmax_out && i2l_conv_smallk_applicable(Cin, Cout))
         return i2l_conv_smallk_run(x, w, bias, y, B, Cin, H, W, Cout, i2l_s(stream));
-    if (!argmax_out && i2l_conv_bf16x3_applicable(Cin, Cout))
+    if (!exact && !argmax_out && i2l_conv_bf16x3_applicable(Cin, Cout))
         return i2l_conv_bf16x3_run(x, w, bias, y, nullptr, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
-    return run_conv(true, x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
+    return run_conv(true, x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream), exact);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -602,10 +604,12 @@ extern "C" size_t i2l_conv_bwd_workspace_bytes(int B, int Cin, int H, int W, int
 
 extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const float* y, const uint8_t* argmax,
                                            const float* dy, float* dx, float* dw, float* db, int B, int Cin, int H,
-                                           int W, int Cout, void* workspace, size_t workspace_bytes,
+                                           int W, int Cout, void* workspace, size_t workspace_bytes, int flags,
                                            i2l_stream_t stream) {
     if (!x || !w || !y || !argmax || !dy || !dw || !db || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2)
         return I2L_ERR_ARG;
+    const bool exact = (flags & I2L_FLAG_EXACT_FP32) != 0;
+    const int split = exact ? 0 : 1;
     const BwdLayout lo = bwd_layout(B, Cin, H, W, Cout);
     if (!workspace || workspace_bytes < lo.total) return I2L_ERR_WORKSPACE;
     char* base = static_cast<char*>(workspace);
@@ -622,7 +626,7 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     gp.W = x; gp.ldw = (long)HW; gp.bsw = (long)(Cin * HW);
     gp.conv_h = H; gp.conv_w = W;
     gp.nz = B;
-    gp.split_bf16 = 1;
+    gp.split_bf16 = split;
     gp.C = dw; gp.ldc = Cin * 9;
     gp.M = Cout; gp.N = Cin * 9; gp.K = (int)HW;
     const bool fused_unpool = !dx && (H % 2) == 0 && (W % 2) == 0 && i2l_gemm_split_bf16_ok(gp);
@@ -660,7 +664,7 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         g.W = x; g.ldw = (long)HW; g.bsw = (long)(Cin * HW);
         g.conv_h = H; g.conv_w = W;
         g.nz = B;
-        g.split_bf16 = 1;
+        g.split_bf16 = split;
         g.C = dw; g.ldc = Cin * 9;
         g.M = Cout; g.N = Cin * 9; g.K = (int)HW;
         if (i2l_gemm_split_bf16_ok(g)) {
@@ -681,7 +685,7 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         g.A = dyp + (size_t)b0 * Cout * HW; g.lda = (long)HW; g.bsa = (long)(Cout * HW);
         g.W = colT; g.ldw = (long)HW; g.bsw = (long)(Cin * 9 * HW);
         g.nz = nb;
-        g.split_bf16 = 1;      // training GEMM: 3-way split bf16 matrix cores where the shape allows (gemm.hip)
+        g.split_bf16 = split;  // training GEMM: 3-way split bf16 matrix cores where the shape allows (gemm.hip)
         g.C = dw; g.ldc = Cin * 9;
         g.M = Cout; g.N = Cin * 9; g.K = (int)HW;
         g.accumulate = b0 > 0 ? 1 : 0;
@@ -689,7 +693,8 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         if (rc != I2L_OK) return rc;
     }
     if (dx) {   // data gradient = conv3x3(dyp, flipped / transposed filter), Cout -> Cin channels
-        const int rc = run_conv(false, dyp, w, nullptr, dx, nullptr, B, Cout, H, W, Cin, base + lo.wpack, lo.wpack_bytes, s);
+        const int rc = run_conv(false, dyp, w, nullptr, dx, nullptr, B, Cout, H, W, Cin, base + lo.wpack, lo.wpack_bytes, s,
+                                exact);
         if (rc != I2L_OK) return rc;
     }
     return I2L_OK;

@@ -480,8 +480,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
 }  // namespace
 
 bool i2l_conv_bf16x3_applicable(int Cin, int Cout) {
-    static const bool exact = getenv("I2L_CONV_EXACT_FP32") != nullptr && atoi(getenv("I2L_CONV_EXACT_FP32")) != 0;
-    return !exact && Cin % CH == 0 && Cout % CO_BLK == 0;
+    return Cin % CH == 0 && Cout % CO_BLK == 0;
 }
 
 size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout) {
@@ -538,8 +537,7 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
 }
 
 bool i2l_conv_smallk_applicable(int Cin, int Cout) {
-    static const bool exact = getenv("I2L_CONV_EXACT_FP32") != nullptr && atoi(getenv("I2L_CONV_EXACT_FP32")) != 0;
-    return !exact && Cin >= 1 && Cin <= 3 && Cout % 32 == 0;
+    return Cin >= 1 && Cin <= 3 && Cout % 32 == 0;
 }
 
 int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,

@@ -1037,8 +1037,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
     p.top_k = top_k; p.top_p = top_p; p.seed = seed; p.probs = probs_out;
 
     // grouped kernel: 4 workgroups share 4 rows, weights fully on chip (decode_group.inc.h)
-    static const bool group_off = getenv("I2L_DECODE_GROUP") != nullptr && atoi(getenv("I2L_DECODE_GROUP")) == 0;
-    if (!group_off && rows_per_wg == 0 && lo.xchg_bytes && select == I2L_SELECT_LOGITS && !h0 && !h_out && !c_out &&
+    if (rows_per_wg == 0 && lo.xchg_bytes && select == I2L_SELECT_LOGITS && !h0 && !h_out && !c_out &&
         steps >= 8 && steps <= 65000) {   // the candidate granule carries step + 1 in 16 bits
         GroupParams gp{};
         gp.w = p.w; gp.B = rows; gp.T = steps; gp.n_groups = lo.n_groups;
@@ -1145,7 +1144,7 @@ extern "C" size_t i2l_beam_workspace_bytes(int images, int beam, int hidden, int
 
 extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspace, int images, int beam, int steps,
                                int start_id, int end_id, void* beam_workspace, size_t beam_workspace_bytes,
-                               int32_t* seq_out, int32_t* len_out, double* score_out, i2l_stream_t stream) {
+                               int32_t* seq_out, int32_t* len_out, double* score_out, int flags, i2l_stream_t stream) {
     int rc = check_weights(w);
     if (rc != I2L_OK) return rc;
     if (!workspace || !beam_workspace || !seq_out || !len_out || images <= 0 || steps <= 0 || beam <= 0)
@@ -1157,10 +1156,9 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
     const Layout lo = make_layout(images, V, E, H, L);
     if (lo.Vp > 64 * 32) return I2L_ERR_UNSUPPORTED;      // top-k exclusion mask: 32 elements per lane
     hipStream_t s = i2l_s(stream);
-    // grouped kernel: 4 workgroups share 12 beam slots, weights fully on chip (beam_group.inc.h); read per call so
-    // that a caller can fall back after a -3 result
-    const char* genv = getenv("I2L_BEAM_GROUP");
-    const bool group_on = !(genv && atoi(genv) == 0);
+    // grouped kernel: 4 workgroups share 12 beam slots, weights fully on chip (beam_group.inc.h); a caller falls back
+    // with I2L_FLAG_NO_GROUP after a -3 result
+    const bool group_on = !(flags & I2L_FLAG_NO_GROUP);
     if (group_on && beam_group_ok(beam, H, L) && V <= 512 && steps <= 65000 &&
         beam_workspace_bytes >= i2l_beam_workspace_bytes(images, beam, H, L, steps)) {
         BeamGroupParams gp{};

@@ -351,8 +351,11 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
     if (tid == 0 && blockIdx.x < 32) for (int i = 0; i < 8; ++i) p.status[8 + blockIdx.x * 8 + i] = (unsigned)st_acc[i];
 #endif
     if (failed) {
+        // loud failure: ids -3 (checked by the host wrappers) and NaN logits (a caller that asked for logits only --
+        // the validation forward -- gets a NaN loss instead of a partly written tensor)
         if (tid == 0) atomicOr(p.status, 1u);
         if (ids_row) for (int tt = tid; tt < T; tt += GNT) ids_row[tt] = -3;
+        if (lrow) for (int tt = 0; tt < T; ++tt) lrow[(size_t)tt * V] = __builtin_nanf("");
         return;
     }
     if (ids_row) for (int tt = t + tid; tt < T; tt += GNT) ids_row[tt] = -1;   // steps never executed (sticky stop)

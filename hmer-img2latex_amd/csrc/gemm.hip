@@ -489,14 +489,9 @@ void plan_bf16x3(int M, int N, long KT, int* S, int* k_chunk) {      // KT = nz 
     *k_chunk = (int)kc;
 }
 
-bool split_bf16_exact_mode() {
-    static const bool exact = getenv("I2L_CONV_EXACT_FP32") != nullptr && atoi(getenv("I2L_CONV_EXACT_FP32")) != 0;
-    return exact;
-}
-
 // can this GEMM run on gemm_bf16x3_kernel?  (single operand pair, K-contiguous operands 16-byte aligned with K % 8 == 0)
 bool bf16x3_applicable(const GemmArgs& g) {
-    if (split_bf16_exact_mode() || g.K < 64 || (g.nz > 1 && (g.K % LBK != 0 || (long)g.nz * g.K > 0x7fffffffl))) return false;
+    if (g.K < 64 || (g.nz > 1 && (g.K % LBK != 0 || (long)g.nz * g.K > 0x7fffffffl))) return false;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     if (g.pool_y) {
         if (!(g.conv_h > 0 && g.a_kc && g.pool_am && (g.conv_w % 8) == 0 && (g.conv_h % 2) == 0 && al16(g.A) && al16(g.pool_y) &&
@@ -592,7 +587,7 @@ extern "C" size_t i2l_linear_workspace_bytes(int M, int K, int N) {
 
 extern "C" int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, float* y,
                                         int M, int K, int N, int relu, void* workspace,
-                                        size_t workspace_bytes, i2l_stream_t stream) {
+                                        size_t workspace_bytes, int flags, i2l_stream_t stream) {
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return I2L_ERR_ARG;
     GemmArgs g = gemm_args();
     g.A = x; g.lda = K;
@@ -601,7 +596,8 @@ extern "C" int i2l_linear_bias_act_fwd(const float* x, const float* w, const flo
     g.C = y; g.ldc = N;
     g.M = M; g.N = N; g.K = K;
     g.relu = relu ? 1 : 0;
-    g.split_bf16 = K >= 2048;                  // long reductions (the encoder FC): bf16 matrix cores, fp32-grade result
+    // long reductions (the encoder FC): bf16 matrix cores, fp32-grade result
+    g.split_bf16 = (K >= 2048 && !(flags & I2L_FLAG_EXACT_FP32)) ? 1 : 0;
     return i2l_gemm(g, workspace, workspace_bytes, i2l_s(stream));
 }
 
@@ -642,7 +638,7 @@ extern "C" size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N) {
 
 extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                                         float* dw, float* db, int M, int K, int N, int relu, void* workspace,
-                                        size_t workspace_bytes, i2l_stream_t stream) {
+                                        size_t workspace_bytes, int flags, i2l_stream_t stream) {
     if (!x || !w || !dy || !dw || !db || (relu && !y) || M <= 0 || K <= 0 || N <= 0) return I2L_ERR_ARG;
     if (!workspace || workspace_bytes < i2l_linear_bwd_workspace_bytes(M, K, N)) return I2L_ERR_WORKSPACE;
     hipStream_t s = i2l_s(stream);
@@ -662,7 +658,7 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
     I2L_CHECK_LAUNCH();
     {   // dw[n][k] = sum_m d[m][n] * x[m][k]
         GemmArgs g = gemm_args();
-        g.split_bf16 = 1;
+        g.split_bf16 = (flags & I2L_FLAG_EXACT_FP32) ? 0 : 1;
         g.A = d; g.lda = N; g.a_kc = 0;
         g.W = x; g.ldw = K; g.w_kc = 0;
         g.C = dw; g.ldc = K;
@@ -672,7 +668,7 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
     }
     if (dx) {   // dx[m][k] = sum_n d[m][n] * w[n][k]
         GemmArgs g = gemm_args();
-        g.split_bf16 = 1;
+        g.split_bf16 = (flags & I2L_FLAG_EXACT_FP32) ? 0 : 1;
         g.A = d; g.lda = N;
         g.W = w; g.ldw = K; g.w_kc = 0;
         g.C = dx; g.ldc = K;

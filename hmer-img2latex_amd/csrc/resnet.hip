@@ -695,29 +695,21 @@ PackLayout pack_layout(int Cout, int Cin, int kh, int kw) {
 }  // namespace
 
 namespace {
-bool stem_fused_enabled() {
-    static const bool on = [] { const char* e = getenv("I2L_RESNET_STEM_FUSED"); return !(e && e[0] == '0'); }();
-    return on;
-}
 bool stem_shape(int Cin, int Cout, int kh, int kw, int stride, int pad) {
     return Cin == 3 && Cout == 64 && kh == 7 && kw == 7 && stride == 2 && pad == 3;
 }
-bool ring_enabled() {
-    static const bool on = [] { const char* e = getenv("I2L_RESNET_RING"); return !(e && e[0] == '0'); }();
-    return on;
-}
-// Stages of the operand ring (I2L_RESNET_RING_DEPTH overrides, 2..4).  Two stages are 64 KB of LDS, so two
+// Stages of the operand ring (I2L_FLAG_RESNET_RING_DEPTH(n) overrides, 2..4).  Two stages are 64 KB of LDS, so two
 // workgroups share a CU and cover each other's waits: measured faster than a deeper ring on every layer
 // that has more tiles than CUs.  With at most one tile per CU only the ring hides latency: 4 stages.
-int ring_depth(int kt, long tiles) {
-    static const int forced = [] { const char* e = getenv("I2L_RESNET_RING_DEPTH"); return e ? atoi(e) : 0; }();
+int ring_depth(int kt, long tiles, int flags) {
+    const int forced = (flags >> 8) & 0xF;
     if (forced >= 2 && forced <= 4) return forced;
     return (tiles <= 256 && kt >= 4) ? 4 : 2;
 }
 template <int NTW, int BK, int NS, bool CONV, bool RES>
 int launch_ring4(const BfGemm& g, int nb_n, int total, hipStream_t s) {
     constexpr int lds = NS * (GM + 64 * NTW) * BK * 2;
-    static const hipError_t attr =
+    const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return I2L_ERR_LAUNCH;
@@ -766,14 +758,14 @@ extern "C" int i2l_conv_bn_bf16_pack(const float* w, const float* bn_weight, con
 }
 
 extern "C" size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
-                                                int pad) {
+                                                int pad, int flags) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return 0;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
     const int Kp = i2l_cdiv(kh * kw * Cin, 8) * 8;
     const bool direct = kh == 1 && kw == 1 && stride == 1 && pad == 0 && Cin % 8 == 0;
     const bool implicit = Cin % 64 == 0;                   // NHWC input gathered inside the GEMM (no im2col image)
-    const bool stem = stem_fused_enabled() && stem_shape(Cin, Cout, kh, kw, stride, pad);
+    const bool stem = !(flags & I2L_FLAG_RESNET_IM2COL_STEM) && stem_shape(Cin, Cout, kh, kw, stride, pad);
     return (direct || implicit || stem) ? 256 : i2l_align((size_t)B * Ho * Wo * Kp * sizeof(bf16_t));
 }
 
@@ -781,10 +773,10 @@ extern "C" size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, in
 // `packed` comes from i2l_conv_bn_bf16_pack for the same conv.
 extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const void* packed, const void* residual,
                                          void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
-                                         int pad, int relu, void* workspace, size_t workspace_bytes,
+                                         int pad, int relu, void* workspace, size_t workspace_bytes, int flags,
                                          i2l_stream_t stream) {
     if (!x || !packed || !y) return I2L_ERR_ARG;
-    const size_t need = i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad);
+    const size_t need = i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, flags);
     if (need == 0) return I2L_ERR_ARG;
     if (!workspace || workspace_bytes < need) return I2L_ERR_WORKSPACE;
     if (!x_is_nchw_f32 && Cin % 8 != 0) return I2L_ERR_UNSUPPORTED;
@@ -801,7 +793,7 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     bf16_t* col = static_cast<bf16_t*>(workspace);
     const size_t M = (size_t)B * Ho * Wo;
     if (M > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
-    if (x_is_nchw_f32 && !residual && stem_fused_enabled() && stem_shape(Cin, Cout, kh, kw, stride, pad)) {
+    if (x_is_nchw_f32 && !residual && !(flags & I2L_FLAG_RESNET_IM2COL_STEM) && stem_shape(Cin, Cout, kh, kw, stride, pad)) {
         const int tiles_x = i2l_cdiv(Wo, ST_TW), tiles_y = i2l_cdiv(Ho, ST_TH);
         const long n_tiles = (long)B * tiles_x * tiles_y;
         if (n_tiles > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
@@ -839,10 +831,10 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     g.C = static_cast<bf16_t*>(y); g.ldc = Cout;
     g.M = (int)M; g.N = Cout; g.K = Kp; g.relu = relu;
     const int gn = Cout <= 64 ? 64 : 128;                  // narrow tile for the 64-channel layers (no wasted MFMAs)
-    if (ring_enabled() && (direct || implicit) && Kp % 64 == 0) {
+    if (!(flags & I2L_FLAG_RESNET_NO_RING) && (direct || implicit) && Kp % 64 == 0) {
         const int nb_n = i2l_cdiv(Cout, gn), nb_m = i2l_cdiv((int)M, GM);
         const long total = (long)nb_n * nb_m;
-        const int depth = ring_depth(Kp / 64, total);
+        const int depth = ring_depth(Kp / 64, total, flags);
         if (total > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
         return gn == 64 ? launch_ring<1>(g, depth, nb_n, (int)total, s) : launch_ring<2>(g, depth, nb_n, (int)total, s);
     }

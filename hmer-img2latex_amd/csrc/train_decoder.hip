@@ -613,11 +613,6 @@ TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
     return o;
 }
 
-bool train_group_enabled() {
-    static const bool off = getenv("I2L_TRAIN_GROUP") != nullptr && atoi(getenv("I2L_TRAIN_GROUP")) == 0;
-    return !off;
-}
-
 int check_w(const i2l_decoder_weights* w) {
     if (!w || !w->embedding || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->w_out || !w->b_out) return I2L_ERR_ARG;
     if (w->vocab <= 0 || w->embed <= 0 || w->hidden <= 0 || w->layers <= 0) return I2L_ERR_ARG;
@@ -659,9 +654,11 @@ extern "C" size_t i2l_decoder_train_workspace_bytes(int B, int T, int vocab, int
 
 extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* enc, const int32_t* tokens, int B, int T,
                                       float dropout_p, uint64_t seed, int attention_path, void* workspace,
-                                      size_t workspace_bytes, float* logits_out, i2l_stream_t stream) {
+                                      size_t workspace_bytes, float* logits_out, int flags, i2l_stream_t stream) {
     int rc = check_w(w);
     if (rc != I2L_OK) return rc;
+    const int split = (flags & I2L_FLAG_EXACT_FP32) ? 0 : 1;
+    const bool group_on = !(flags & I2L_FLAG_NO_GROUP);
     if (!enc || !tokens || !logits_out || B <= 0 || T <= 0 || dropout_p < 0.f || dropout_p >= 1.f) return I2L_ERR_ARG;
     const int V = w->vocab, E = w->embed, H = w->hidden, L = w->layers;
     const TLayout lo = make_tlayout(B, T, V, E, H, L);
@@ -677,7 +674,7 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
     I2L_CHECK_LAUNCH();
     {   // GX = X @ W_ih_0^T + b_ih_0 + b_hh_0, gate-interleaved
         GemmArgs g = gemm_args();
-            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
+        g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = F(lo.X); g.lda = 2 * E;
         g.W = w->w_ih[0]; g.ldw = 2 * E;
         g.bias = w->b_ih[0]; g.bias2 = w->b_hh[0];
@@ -711,7 +708,7 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
         if (lds > 64 * 1024) return I2L_ERR_UNSUPPORTED;
         dim3 grid(i2l_cdiv(B, R));
         bool done = false;
-        if (lo.xchg_bytes && T >= 8 && train_group_enabled()) {  // 4 workgroups share 4 rows, W_hh in registers
+        if (lo.xchg_bytes && T >= 8 && group_on) {  // 4 workgroups share 4 rows, W_hh in registers
             TrainGroupFwd gp{};
             gp.B = B; gp.T = T; gp.n_groups = lo.n_groups; gp.GX = p.GX; gp.WhhT = p.WhhT[0];
             gp.ACT = p.ACT[0]; gp.C = p.C[0]; gp.Hout = p.Hout[0]; gp.Hprev = p.Hprev[0];
@@ -743,7 +740,7 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
     I2L_CHECK_LAUNCH();
     {   // logits = Hdrop @ W_out^T + b_out
         GemmArgs g = gemm_args();
-            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
+        g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = F(lo.Hdrop); g.lda = H;
         g.W = w->w_out; g.ldw = H;
         g.bias = w->b_out;
@@ -780,9 +777,11 @@ extern "C" size_t i2l_ce_workspace_bytes(int rows) {
 extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t* tokens, int B, int T, float dropout_p,
                                       uint64_t seed, int attention_path, void* workspace, size_t workspace_bytes,
                                       const float* dlogits, const i2l_decoder_grads* gr, float* denc_out,
-                                      i2l_stream_t stream) {
+                                      int flags, i2l_stream_t stream) {
     int rc = check_w(w);
     if (rc != I2L_OK) return rc;
+    const int split = (flags & I2L_FLAG_EXACT_FP32) ? 0 : 1;
+    const bool group_on = !(flags & I2L_FLAG_NO_GROUP);
     if (!tokens || !dlogits || !gr || !denc_out || B <= 0 || T <= 0) return I2L_ERR_ARG;
     if (!gr->embedding || !gr->w_ih || !gr->w_hh || !gr->b_ih || !gr->b_hh || !gr->w_out || !gr->b_out) return I2L_ERR_ARG;
     const int V = w->vocab, E = w->embed, H = w->hidden, L = w->layers;
@@ -797,7 +796,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
 
     {   // dW_out[v][h] = sum_bt dlogits[bt][v] * Hdrop[bt][h]
         GemmArgs g = gemm_args();
-            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
+        g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = dlogits; g.lda = V; g.a_kc = 0;
         g.W = F(lo.Hdrop); g.ldw = H; g.w_kc = 0;
         g.C = gr->w_out; g.ldc = H;
@@ -809,7 +808,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     if (rc != I2L_OK) return rc;
     {   // dHdrop[bt][h] = sum_v dlogits[bt][v] * W_out[v][h]
         GemmArgs g = gemm_args();
-            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
+        g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = dlogits; g.lda = V;
         g.W = w->w_out; g.ldw = H; g.w_kc = 0;
         g.C = F(lo.dHdrop); g.ldc = H;
@@ -838,7 +837,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         if (lds > 64 * 1024) return I2L_ERR_UNSUPPORTED;
         dim3 grid(i2l_cdiv(B, R));
         bool done = false;
-        if (lo.xchg_bytes && T >= 8 && train_group_enabled()) {
+        if (lo.xchg_bytes && T >= 8 && group_on) {
             TrainGroupBwd gp{};
             gp.B = B; gp.T = T; gp.n_groups = lo.n_groups; gp.ACT = p.ACT[0]; gp.C = p.C[0]; gp.dHtop = p.dHtop;
             gp.Whh = p.Whh[0]; gp.DG = p.DG[0];
@@ -869,7 +868,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         const float* DGl = F(lo.DG[l]);
         {   // dW_ih_l[n][k] = sum_bt DG[bt][n] * In[bt][k]
             GemmArgs g = gemm_args();
-            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
+        g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
             g.A = DGl; g.lda = G; g.a_kc = 0;
             if (l == 0) { g.W = F(lo.X); g.ldw = 2 * E; g.N = 2 * E; }
             else { g.W = F(lo.Hdrop); g.ldw = H; g.N = H; }     // placeholder, replaced below for l > 0
@@ -889,7 +888,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         }
         {   // dW_hh_l[n][k] = sum_bt DG[bt][n] * h_{t-1}[bt][k]
             GemmArgs g = gemm_args();
-            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
+        g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
             g.A = DGl; g.lda = G; g.a_kc = 0;
             g.W = F(lo.Hprev[l]); g.ldw = H; g.w_kc = 0;
             g.C = gr->w_hh[l]; g.ldc = H;
@@ -902,7 +901,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     }
     {   // dX[bt][k] = sum_n DG0[bt][n] * W_ih_0[n][k]
         GemmArgs g = gemm_args();
-            g.split_bf16 = 1;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
+        g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = F(lo.DG[0]); g.lda = G;
         g.W = w->w_ih[0]; g.ldw = 2 * E; g.w_kc = 0;
         g.C = F(lo.dX); g.ldc = 2 * E;

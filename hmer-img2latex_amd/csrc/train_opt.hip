@@ -6,7 +6,10 @@
 //   total  = ||g||_2 over all parameters            nn.utils.clip_grad_norm_: coef = min(1, max_norm/(total+1e-6))
 //   g      = g * coef + weight_decay * p            torch.optim.Adam's L2 is coupled (added to the gradient)
 //   m, v, p updated with bias correction            denom = sqrt(v)/sqrt(1-b2^t) + eps ; p -= lr/(1-b1^t) * m/denom
-// Two launches, no host synchronisation; the sum of squares is reduced in a fixed order (deterministic).
+// Three launches, no host synchronisation; the sum of squares is reduced in a fixed order (deterministic).
+// Non-finite total norm (Inf / NaN gradients: an fp16-scaled overflow, or the NaN a grouped training kernel writes
+// when one of its bounded waits expires) => the call is a no-op on p, m, v: stats[3] = 1 and a counter in the
+// workspace remembers how many calls were skipped, so the bias correction keeps counting APPLIED steps only.
 #include <math.h>
 
 #include "common.h"
@@ -32,10 +35,13 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// stats_out[0] = total gradient norm (after the 1/count scaling), [1] = clip coefficient, [2] = 1/count
+// stats_out[0] = total gradient norm (after the 1/count scaling), [1] = clip coefficient, [2] = 1/count,
+// [3] = 1 when the update is skipped; coefs (workspace) = {apply?, lr / bc1, sqrt(bc2)} of the applied-step number
 __global__ __launch_bounds__(256) void norm_final_kernel(const double* __restrict__ partial, int nblk,
                                                          const float* __restrict__ count_ptr, float max_norm,
-                                                         float* __restrict__ stats_out) {
+                                                         float* __restrict__ stats_out, unsigned* __restrict__ skipped,
+                                                         int step, float lr, float b1, float b2,
+                                                         float* __restrict__ coefs) {
     __shared__ double red[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
@@ -51,18 +57,28 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double* __restric
         const float total = (float)sqrt(red[0]) * inv;
         float coef = 1.f;
         if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
+        const bool skip = !(total <= 3.0e38f);           // NaN or Inf
+        unsigned nskip = *skipped;
+        if (skip) { coef = 0.f; *skipped = ++nskip; }
         stats_out[0] = total;
         stats_out[1] = coef;
         stats_out[2] = inv;
+        stats_out[3] = skip ? 1.f : 0.f;
+        int applied = step - (int)nskip;                 // optimizer step number among the APPLIED updates
+        if (applied < 1) applied = 1;
+        coefs[0] = skip ? 0.f : 1.f;
+        coefs[1] = lr / (1.f - powf(b1, (float)applied));
+        coefs[2] = sqrtf(1.f - powf(b2, (float)applied));
     }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                   const float* __restrict__ stats, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2_sqrt) {
+                                                   const float* __restrict__ stats, const float* __restrict__ coefs,
+                                                   float b1, float b2, float eps, float wd) {
+    if (coefs[0] == 0.f) return;                     // non-finite gradients: leave p, m, v untouched
     const float gs = stats[1] * stats[2];            // clip coefficient * 1/count
-    const float step = lr / bc1;
+    const float step = coefs[1], bc2_sqrt = coefs[2];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float pi = p[i];
         const float gi = g[i] * gs + wd * pi;
@@ -76,28 +92,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 }  // namespace
 
-extern "C" size_t i2l_optimizer_workspace_bytes(void) { return i2l_align(SQ_BLOCKS * sizeof(double)); }
+// workspace: [SQ_BLOCKS doubles of partial sums][256 B: skipped-call counter, 3 step coefficients]
+extern "C" size_t i2l_optimizer_workspace_bytes(void) { return i2l_align(SQ_BLOCKS * sizeof(double)) + 256; }
 
 extern "C" int i2l_grad_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                         size_t n, const float* count_ptr, float max_norm, float lr, float beta1,
                                         float beta2, float eps, float weight_decay, int step, void* workspace,
                                         size_t workspace_bytes, float* stats_out, i2l_stream_t stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !stats_out || n == 0 || step < 1) return I2L_ERR_ARG;
-    if (!workspace || workspace_bytes < SQ_BLOCKS * sizeof(double)) return I2L_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < i2l_optimizer_workspace_bytes()) return I2L_ERR_WORKSPACE;
     hipStream_t s = i2l_s(stream);
     double* partial = static_cast<double*>(workspace);
+    char* tail = static_cast<char*>(workspace) + i2l_align(SQ_BLOCKS * sizeof(double));
+    unsigned* skipped = reinterpret_cast<unsigned*>(tail);
+    float* coefs = reinterpret_cast<float*>(tail + 16);
     size_t nb = (n + 255) / 256;
     const int nblk = (int)(nb > (size_t)SQ_BLOCKS ? SQ_BLOCKS : nb);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, s, grads, n, partial);
     I2L_CHECK_LAUNCH();
     hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, nblk, count_ptr, max_norm,
-                       stats_out);
+                       stats_out, skipped, step, lr, beta1, beta2, coefs);
     I2L_CHECK_LAUNCH();
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     const int ablk = (int)(nb > 4096 ? 4096 : nb);
     hipLaunchKernelGGL(adam_kernel, dim3(ablk), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
-                       (const float*)stats_out, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+                       (const float*)stats_out, (const float*)coefs, beta1, beta2, eps, weight_decay);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }

@@ -20,6 +20,12 @@ STOP_NONE, STOP_STICKY = 0, 1
 SELECT_LOGITS, SELECT_SOFTMAX, SELECT_SAMPLE = 0, 1, 2
 PREP_WEIGHTS, PREP_ROWS, PREP_ALL = 1, 2, 3
 MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
+# kernel-selection flags (include/img2latex_hip.h I2L_FLAG_*): explicit arguments, the library reads no environment
+FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0x1, 0x2, 0x4, 0x8
+
+
+def flag_resnet_ring_depth(n: int) -> int:
+    return (int(n) & 0xF) << 8
 
 
 class DecoderWeights(ctypes.Structure):
@@ -40,22 +46,23 @@ _SIGNATURES = {
     "i2l_error_string": (c_char_p, [c_int]),
     "i2l_conv_workspace_bytes": (c_size_t, [c_int, c_int]),
     "i2l_conv3x3_relu_pool2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                           c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                           c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "i2l_conv_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "i2l_conv3x3_relu_pool2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_int,
+                                           c_void_p]),
     "i2l_linear_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "i2l_linear_bias_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                        c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                        c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "i2l_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "i2l_linear_bias_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                        c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_size_t, c_int, c_void_p]),
     "i2l_conv_bf16_packed_bytes": (c_size_t, [c_int] * 4),
     "i2l_conv_bn_bf16_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t,
                                       c_int, c_int, c_int, c_int, c_void_p]),
-    "i2l_conv_bf16_workspace_bytes": (c_size_t, [c_int] * 9),
+    "i2l_conv_bf16_workspace_bytes": (c_size_t, [c_int] * 10),
     "i2l_conv_bn_act_bf16_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 10 +
-                                 [c_void_p, c_size_t, c_void_p]),
+                                 [c_void_p, c_size_t, c_int, c_void_p]),
     "i2l_maxpool3x3s2_bf16_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_global_avgpool_bf16_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -71,14 +78,14 @@ _SIGNATURES = {
                                   c_void_p]),
     "i2l_beam_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "i2l_beam_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "i2l_attention_context_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                           c_int, c_int, c_void_p]),
     "i2l_decoder_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "i2l_decoder_train_fwd": (c_int, [POINTER(DecoderWeights), c_void_p, c_void_p, c_int, c_int, c_float, c_uint64,
-                                      c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+                                      c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "i2l_decoder_train_bwd": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_float, c_uint64, c_int,
-                                      c_void_p, c_size_t, c_void_p, POINTER(DecoderGrads), c_void_p, c_void_p]),
+                                      c_void_p, c_size_t, c_void_p, POINTER(DecoderGrads), c_void_p, c_int, c_void_p]),
     "i2l_optimizer_workspace_bytes": (c_size_t, []),
     "i2l_grad_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
                                         c_float, c_float, c_float, c_float, c_int, c_void_p, c_size_t, c_void_p,
@@ -137,7 +144,7 @@ def check_ids(ids_host: torch.Tensor) -> torch.Tensor:
     first = ids_host[:, 0] if ids_host.dim() == 2 else ids_host
     if first.numel() and bool((first == -3).any()):
         raise RuntimeError("img2latex_amd: grouped decode timed out waiting for a peer workgroup "
-                           "(GPU oversubscribed?); set I2L_DECODE_GROUP=0 to use the row-per-workgroup kernel")
+                           "(GPU oversubscribed?); pass rows_per_workgroup=1 to use the row-per-workgroup kernel")
     return ids_host
 
 

@@ -52,9 +52,11 @@ def decoder_train_forward(decoder, enc, tokens, seed):
     p = float(decoder.dropout) if decoder.training else 0.0
     _lib.check(L.i2l_decoder_train_fwd(ctypes.byref(w), enc.data_ptr(), tokens.data_ptr(), B, T, p, int(seed),
                                        1 if decoder.use_attention else 0, ws.data_ptr(), nbytes,
-                                       logits.data_ptr(), _lib.stream_ptr()), "decoder_train_fwd")
+                                       logits.data_ptr(), int(decoder.kernel_flags), _lib.stream_ptr()),
+               "decoder_train_fwd")
     del keep
-    return logits, dict(ws=ws, tokens=tokens, seed=int(seed), p=p, enc_shape=tuple(enc.shape))
+    return logits, dict(ws=ws, tokens=tokens, seed=int(seed), p=p, enc_shape=tuple(enc.shape),
+                        flags=int(decoder.kernel_flags))
 
 
 def decoder_train_backward(dec, state, dlogits, grads):
@@ -79,7 +81,8 @@ def decoder_train_backward(dec, state, dlogits, grads):
     ws = state["ws"]
     _lib.check(L.i2l_decoder_train_bwd(ctypes.byref(w), tokens.data_ptr(), B, T, state["p"], state["seed"],
                                        1 if dec.use_attention else 0, ws.data_ptr(), ws.numel(),
-                                       dlogits.data_ptr(), ctypes.byref(g), denc.data_ptr(), _lib.stream_ptr()),
+                                       dlogits.data_ptr(), ctypes.byref(g), denc.data_ptr(), state["flags"],
+                                       _lib.stream_ptr()),
                "decoder_train_bwd")
     del keep
     return denc
@@ -130,7 +133,7 @@ def encoder_train_backward(enc, state, denc, grads):
     _lib.check(L.i2l_linear_bias_act_bwd(feat.data_ptr(), lin.weight.detach().data_ptr(), state["out"].data_ptr(),
                                          denc.data_ptr(), dfeat.data_ptr(), grads["embedding_layer.weight"].data_ptr(),
                                          grads["embedding_layer.bias"].data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
-                                         _lib.stream_ptr()), "linear_bias_act_bwd")
+                                         enc.kernel_flags, _lib.stream_ptr()), "linear_bias_act_bwd")
     dy = dfeat
     for i in reversed(range(len(enc.conv_filters))):
         conv = enc.cnn_layers[3 * i]
@@ -143,5 +146,5 @@ def encoder_train_backward(enc, state, denc, grads):
             xin.data_ptr(), conv.weight.detach().data_ptr(), blocks[i].data_ptr(), amax[i].data_ptr(),
             dy.data_ptr(), _lib.ptr(dx), grads[f"cnn_layers.{3 * i}.weight"].data_ptr(),
             grads[f"cnn_layers.{3 * i}.bias"].data_ptr(), B, cin, h, w, conv.out_channels, ws.data_ptr(), nbytes,
-            _lib.stream_ptr()), "conv3x3_relu_pool2_bwd")
+            enc.kernel_flags, _lib.stream_ptr()), "conv3x3_relu_pool2_bwd")
         dy = dx

@@ -50,6 +50,7 @@ class CNNEncoder(nn.Module):
         self.embedding_layer = nn.Linear(self.flattened_size, embedding_dim)
         self.activation = nn.ReLU()
         self._ws: Optional[torch.Tensor] = None
+        self.kernel_flags = 0      # _lib.FLAG_EXACT_FP32: exact fp32 kernels instead of the 3 x bf16 split
 
     def _workspace(self, nbytes: int, device) -> Optional[torch.Tensor]:
         if nbytes == 0:
@@ -81,7 +82,7 @@ class CNNEncoder(nn.Module):
                 argmax_out.append(amax)
             _lib.check(L.i2l_conv3x3_relu_pool2_fwd(x.data_ptr(), wt.data_ptr(), bs.data_ptr(), y.data_ptr(),
                                                     _lib.ptr(amax), B, cin, h, w, conv.out_channels, _lib.ptr(ws),
-                                                    nbytes, _lib.stream_ptr()),
+                                                    nbytes, self.kernel_flags, _lib.stream_ptr()),
                        "conv3x3_relu_pool2_fwd")
             _lib.mark(f"conv{i}")
             outs.append(y)
@@ -110,7 +111,7 @@ class CNNEncoder(nn.Module):
         wt = _lib.require_gpu(self.embedding_layer.weight.detach(), "embedding_layer.weight")
         bs = _lib.require_gpu(self.embedding_layer.bias.detach(), "embedding_layer.bias")
         _lib.check(L.i2l_linear_bias_act_fwd(feat.data_ptr(), wt.data_ptr(), bs.data_ptr(), out.data_ptr(),
-                                             B, K, E, 1, _lib.ptr(ws), nbytes, _lib.stream_ptr()),
+                                             B, K, E, 1, _lib.ptr(ws), nbytes, self.kernel_flags, _lib.stream_ptr()),
                    "linear_bias_act_fwd")
         _lib.mark("fc")
         return out

@@ -80,6 +80,7 @@ class LSTMDecoder(nn.Module):
         self._ws: Optional[torch.Tensor] = None      # workspace of the CURRENT stream (see _select_workspace)
         self._ws_key = None          # (rows, weight versions) the weight images in _ws were built for
         self._ws_by_stream = {}      # stream handle -> (workspace, key): concurrent decodes must not share one
+        self.kernel_flags = 0        # training kernels: _lib.FLAG_NO_GROUP / _lib.FLAG_EXACT_FP32
 
     # ------------------------------------------------------------------ plumbing
     def _weights_struct(self):

@@ -102,6 +102,8 @@ class ResNetEncoder(nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._packed = {}          # id(conv) -> (version key, packed bf16 filter + folded BatchNorm)
         self.cache_packed_weights = True
+        self.kernel_flags = 0      # _lib.FLAG_RESNET_NO_RING / FLAG_RESNET_IM2COL_STEM / flag_resnet_ring_depth(n)
+        self.trace = None          # a list here receives (conv, bn, x, residual, y, relu, nchw_f32) of every launch
 
     # ------------------------------------------------------------------
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -117,12 +119,14 @@ class ResNetEncoder(nn.Module):
         L = _lib.lib()
         packed = self._packed_weights(conv, bn, x.device)
         y = torch.empty((B, Ho, Wo, conv.out_channels), dtype=torch.bfloat16, device=x.device)
-        nbytes = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, conv.out_channels, k, k, s, pd)
+        nbytes = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, conv.out_channels, k, k, s, pd, self.kernel_flags)
         ws = self._workspace(nbytes, x.device)
         _lib.check(L.i2l_conv_bn_act_bf16_fwd(
             x.data_ptr(), 1 if nchw_f32 else 0, packed.data_ptr(), _lib.ptr(residual), y.data_ptr(), B, H, W, Cin,
-            conv.out_channels, k, k, s, pd, 1 if relu else 0, ws.data_ptr(), nbytes, _lib.stream_ptr()),
-            "conv_bn_act_bf16_fwd")
+            conv.out_channels, k, k, s, pd, 1 if relu else 0, ws.data_ptr(), nbytes, self.kernel_flags,
+            _lib.stream_ptr()), "conv_bn_act_bf16_fwd")
+        if self.trace is not None:
+            self.trace.append((conv, bn, x, residual, y, relu, nchw_f32))
         return y, (B, Ho, Wo, conv.out_channels)
 
     def _packed_weights(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, device) -> torch.Tensor:
@@ -195,6 +199,6 @@ class ResNetEncoder(nn.Module):
         ws = self._workspace(nbytes, feat.device)
         _lib.check(L.i2l_linear_bias_act_fwd(feat.data_ptr(), self.embedding_layer.weight.detach().data_ptr(),
                                              self.embedding_layer.bias.detach().data_ptr(), out.data_ptr(), B, K, E, 1,
-                                             ws.data_ptr(), nbytes, _lib.stream_ptr()), "linear_bias_act_fwd")
+                                             ws.data_ptr(), nbytes, 0, _lib.stream_ptr()), "linear_bias_act_fwd")
         _lib.mark("fc")
         return out

@@ -8,7 +8,6 @@ device->host copy of the ids at the end instead of a sync per step).
 from __future__ import annotations
 
 import ctypes
-import os
 import warnings
 from typing import Dict, List, Optional
 
@@ -86,22 +85,31 @@ class Seq2SeqModel(nn.Module):
                                                 want_logits=want_logits, rows_per_workgroup=rows_per_workgroup)
         return ids, logits
 
+    def greedy_ids_host(self, encoder_output: torch.Tensor, start_token_id: int, end_token_id: int, max_length: int,
+                        temperature: float = 1.0, stop: int = _lib.STOP_NONE, select: int = _lib.SELECT_LOGITS
+                        ) -> torch.Tensor:
+        """greedy_ids + the ONE device->host copy of the search, with the timeout fallback both callers
+        (_greedy_search and Predictor.predict_batch_ids) share: the grouped kernel needs its 4 members resident
+        together; on a GPU shared with other work (fewer than 32 free CUs) a bounded wait can expire (ids -3) ->
+        run the row-per-workgroup HIP kernel, which needs no partner."""
+        ids, _ = self.greedy_ids(encoder_output, start_token_id, end_token_id, max_length, temperature, stop=stop,
+                                 select=select)
+        ids = ids.cpu()
+        if _lib.ids_timed_out(ids):
+            warnings.warn("img2latex_amd: grouped decode timed out (GPU oversubscribed?); "
+                          "re-running on the row-per-workgroup kernel", RuntimeWarning)
+            ids, _ = self.greedy_ids(encoder_output, start_token_id, end_token_id, max_length, temperature, stop=stop,
+                                     select=select, rows_per_workgroup=1)
+            ids = _lib.check_ids(ids.cpu())
+        return ids
+
     def _greedy_search(self, encoder_output: torch.Tensor, start_token_id: int, end_token_id: int,
                        max_length: int, temperature: float, top_k: int, top_p: float):
         """seq2seq.py:192-232.  top_k / top_p are accepted and ignored, as in the reference.
         The loop stops when ALL rows emit END in the same step (:220); the kernel runs the
         rows independently, so that step is located in the ids afterwards."""
         B = encoder_output.shape[0]
-        ids, _ = self.greedy_ids(encoder_output, start_token_id, end_token_id, max_length, temperature)
-        ids = ids.cpu()                                           # the ONE device->host sync of the search
-        if _lib.ids_timed_out(ids):
-            # the grouped kernel needs its 4 members resident together; on a GPU shared with other work (fewer than
-            # 32 free CUs) a bounded wait can expire -> run the row-per-workgroup HIP kernel, which needs no partner
-            warnings.warn("img2latex_amd: grouped decode timed out (GPU oversubscribed?); "
-                          "re-running on the row-per-workgroup kernel", RuntimeWarning)
-            ids, _ = self.greedy_ids(encoder_output, start_token_id, end_token_id, max_length, temperature,
-                                     rows_per_workgroup=1)
-            ids = _lib.check_ids(ids.cpu())
+        ids = self.greedy_ids_host(encoder_output, start_token_id, end_token_id, max_length, temperature)
         all_end = (ids == end_token_id).all(dim=0)
         steps = int(all_end.nonzero()[0]) + 1 if bool(all_end.any()) else max_length
         rows = ids[:, :steps].tolist()
@@ -122,9 +130,10 @@ class Seq2SeqModel(nn.Module):
         return self.beam_search_batch(encoder_output, start_token_id, end_token_id, max_length, beam_size)[0]
 
     def beam_search_batch(self, encoder_output: torch.Tensor, start_token_id: int, end_token_id: int,
-                          max_length: int, beam_size: int, return_scores: bool = False):
+                          max_length: int, beam_size: int, return_scores: bool = False, flags: int = 0):
         """N independent batch-1 beam searches in one launch (BASELINE config 3): element j
-        equals ``inference(image[j:j+1], beam_size=k)`` of the reference."""
+        equals ``inference(image[j:j+1], beam_size=k)`` of the reference.  ``flags``: _lib.FLAG_NO_GROUP selects
+        the one-workgroup-per-image kernel (the automatic fallback when the grouped kernel times out)."""
         if beam_size > _lib.MAX_BEAM:
             raise NotImplementedError(f"img2latex_amd: beam_size <= {_lib.MAX_BEAM} (got {beam_size})")
         dec = self.decoder
@@ -136,26 +145,18 @@ class Seq2SeqModel(nn.Module):
         seq = torch.empty((n, max_length + 1), dtype=torch.int32, device=dev)
         ln = torch.empty((n,), dtype=torch.int32, device=dev)
         score = torch.empty((n,), dtype=torch.float64, device=dev)
-        def launch():
+        def launch(fl):
             _lib.check(L.i2l_beam_decode(ctypes.byref(w), dec._ws.data_ptr(), n, beam_size, max_length,
                                          int(start_token_id), int(end_token_id), bws.data_ptr(), nbytes,
-                                         seq.data_ptr(), ln.data_ptr(), score.data_ptr(), _lib.stream_ptr()),
+                                         seq.data_ptr(), ln.data_ptr(), score.data_ptr(), int(fl), _lib.stream_ptr()),
                        "beam_decode")
-        launch()
+        launch(flags)
         seq_h, ln_h = seq.cpu(), ln.cpu()
         if min(ln_h.tolist()) <= -3:
             # the grouped kernel needs its four workgroups resident together; on a GPU shared with other work a
             # poll can time out (len -3): run the one-workgroup-per-image kernel instead
             warnings.warn("img2latex_amd: grouped beam search timed out, re-running with one workgroup per image")
-            prev = os.environ.get("I2L_BEAM_GROUP")
-            os.environ["I2L_BEAM_GROUP"] = "0"
-            try:
-                launch()
-            finally:
-                if prev is None:
-                    del os.environ["I2L_BEAM_GROUP"]
-                else:
-                    os.environ["I2L_BEAM_GROUP"] = prev
+            launch(flags | _lib.FLAG_NO_GROUP)
             seq_h, ln_h = seq.cpu(), ln.cpu()
         del keep
         lens = ln_h.tolist()                                   # one conversion each, then plain list slices

@@ -21,6 +21,14 @@ def shard_batch(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rank_of(group=None) -> int:
+    """This process's data-parallel rank (0 when torch.distributed is not initialised)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group)
+    return 0
+
+
 def all_reduce_gradients(flat: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM all-reduce of the flat buffer [grads..., loss_sum, count]; a no-op when
     torch.distributed is not initialised (single GPU)."""

@@ -91,29 +91,22 @@ def _lev_similarity(raw_distance: int, rows: int, cols: int) -> float:
 
 
 def _bleu_from_counts(match: Sequence[int], gen_len: int, true_len: int, n: int) -> float:
-    """metrics.py:113-181 with matching_grams_sum supplied by the kernel."""
-    if gen_len == 0 or true_len == 0:
+    """BLEU-n from the kernel's clipped n-gram match counts (i2l_sequence_metrics).  Bit-identical to the
+    reference's score (metrics.py:113-181) because the float64 operations run in the same order: each
+    precision is ONE division match / (gen_len - g + 1); their logs are added left to right starting from
+    0.0; one division by n; one exp; the brevity factor exp(1 - true_len / gen_len) multiplies from the left."""
+    if min(gen_len, true_len) == 0:
         return 0.0
-    scores = []
-    for gram_size in range(1, n + 1):
-        if gen_len < gram_size or true_len < gram_size:
-            scores.append(0.0)
-            continue
-        scores.append(int(match[gram_size - 1]) / (gen_len - gram_size + 1))
-    for gram_score in scores:
-        if gram_score == 0.0:
+    log_sum = 0.0
+    for g in range(1, n + 1):
+        hits = int(match[g - 1]) if min(gen_len, true_len) >= g else 0
+        if hits == 0:                       # a zero precision zeroes the geometric mean (also: too short for g-grams)
             return 0.0
-    geo_mean = 0.0
-    for gram_score in scores:
-        geo_mean += math.log(gram_score)
-    geo_mean = math.exp(geo_mean / n)
-    if gen_len < true_len:
-        try:
-            brevity_penalty = math.exp(1.0 - true_len / gen_len)
-            return brevity_penalty * geo_mean
-        except ZeroDivisionError:
-            return 0.0
-    return geo_mean
+        log_sum += math.log(hits / (gen_len - g + 1))
+    score = math.exp(log_sum / n)
+    if gen_len >= true_len:
+        return score
+    return math.exp(1.0 - true_len / gen_len) * score
 
 
 def levenshtein_distance(sequence_one: List[int], sequence_two: List[int]) -> float:

@@ -118,12 +118,12 @@ class Predictor:
                 tok0 = torch.full((enc.shape[0],), int(start), dtype=torch.int32, device=enc.device)
                 ids, _ = self.model.decoder.sample_steps(enc, max_length, tok0, temperature, top_k, top_p, seed,
                                                          stop=_lib.STOP_STICKY, end_id=end)
-            else:
-                ids, _ = self.model.greedy_ids(enc, start, end, max_length, temperature, stop=_lib.STOP_STICKY,
-                                               select=_lib.SELECT_SOFTMAX)
-        end, start = self.tokenizer.end_token_id, self.tokenizer.start_token_id
+                ids = _lib.check_ids(ids.cpu())
+            else:       # same timeout fallback as Seq2SeqModel._greedy_search
+                ids = self.model.greedy_ids_host(enc, start, end, max_length, temperature, stop=_lib.STOP_STICKY,
+                                                 select=_lib.SELECT_SOFTMAX)
         out = []
-        for row in _lib.check_ids(ids.cpu()).tolist():
+        for row in ids.tolist():
             row = [t for t in row if t >= 0]
             out.append([start] + (row[: row.index(end)] if end in row else row))
         return out

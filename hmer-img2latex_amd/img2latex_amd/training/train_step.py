@@ -19,7 +19,7 @@ import torch
 from .. import _lib
 from ..model._train_fn import (decoder_train_backward, decoder_train_forward, encoder_train_backward,
                                encoder_train_forward)
-from .dp import all_reduce_gradients, broadcast_parameters
+from .dp import all_reduce_gradients, broadcast_parameters, rank_of
 
 
 class TrainStep:
@@ -32,6 +32,7 @@ class TrainStep:
         self.group = process_group
         self.step_count = 0
         self.seed = seed
+        self.rank = rank_of(process_group)           # mixed into the dropout seed: every rank draws its own masks
         params = [p for p in model.parameters()]
         if not params or not params[0].is_cuda:
             raise RuntimeError("img2latex_amd: TrainStep needs the model on a ROCm device (no CPU fallback)")
@@ -58,7 +59,8 @@ class TrainStep:
                 self.grad_views[name] = self.flat_grads[o:o + p.numel()].view_as(p)
         broadcast_parameters(self.flat_params, 0, self.group)
         L = _lib.lib()
-        self._opt_ws = torch.empty(L.i2l_optimizer_workspace_bytes(), dtype=torch.uint8, device=dev)
+        # zeroed once: besides scratch it carries the count of skipped (non-finite) updates across calls
+        self._opt_ws = torch.zeros(L.i2l_optimizer_workspace_bytes(), dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------
     def forward_backward(self, images: torch.Tensor, formulas: torch.Tensor) -> torch.Tensor:
@@ -70,7 +72,9 @@ class TrainStep:
         tokens_in = formulas[:, :-1].contiguous()                    # seq2seq.py:115-120
         targets = formulas[:, 1:].contiguous()                       # trainer.py:306
         B, T = tokens_in.shape
-        self.step_seed = (self.seed * 1000003 + self.step_count) & 0x3FFFFFFFFFFFFFFF
+        # one dropout stream per (seed, optimizer step, data-parallel rank): the kernels hash the LOCAL element index,
+        # so without the rank every replica would reuse rank 0's masks for its own rows
+        self.step_seed = ((self.seed * 1000003 + self.step_count) * 4099 + self.rank) & 0x3FFFFFFFFFFFFFFF
         enc, enc_state = encoder_train_forward(model.encoder, images)
         logits, dec_state = decoder_train_forward(model.decoder, enc, tokens_in, self.step_seed)
         V = logits.shape[-1]
@@ -104,20 +108,31 @@ class TrainStep:
             torch.autograd.graph.increment_version(p)
 
     def step(self, images: torch.Tensor, formulas: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """trainer.py:303-343 for one batch.  Returns device tensors (no sync): loss, total_norm, count."""
+        """trainer.py:303-343 for one batch.  Returns device tensors (no sync): loss, total_norm, count, skipped.
+        ``skipped`` is 1.0 when the gradients were not finite (e.g. a grouped recurrence kernel timed out on a shared
+        GPU and poisoned its outputs with NaN): the fused clip + Adam kernel then leaves parameters and moments
+        untouched -- on every rank, since the all-reduce spreads the NaN -- and the caller may simply repeat the
+        batch, if it keeps happening with ``model.decoder.kernel_flags |= FLAG_NO_GROUP``."""
         self.model.train()
         self.forward_backward(images, formulas)
         self.apply()
         count = self.flat_grads[self.n + 1]
-        return dict(loss=self.flat_grads[self.n] / count.clamp(min=1.0), total_norm=self.stats[0], count=count)
+        return dict(loss=self.flat_grads[self.n] / count.clamp(min=1.0), total_norm=self.stats[0], count=count,
+                    skipped=self.stats[3])
+
+    def applied_steps(self) -> int:
+        """Optimizer steps actually applied (host sync): step_count minus the skipped, non-finite ones."""
+        skipped = int(self._opt_ws[-256:-252].view(torch.int32).item())
+        return self.step_count - skipped
 
     # ------------------------------------------------------------------ checkpoint compatibility
     def optimizer_state_dict(self) -> Dict:
         """torch.optim.Adam.state_dict() layout (what trainer.py:213 stores): resuming in the reference works."""
         state, params = {}, []
+        applied = self.applied_steps()
         for i, (name, p) in enumerate(self.model.named_parameters()):
             o = self.offsets[name]
-            state[i] = {"step": torch.tensor(float(self.step_count)),
+            state[i] = {"step": torch.tensor(float(applied)),
                         "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).detach().cpu().clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view_as(p).detach().cpu().clone()}
             params.append(i)
@@ -136,6 +151,7 @@ class TrainStep:
             self.exp_avg[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
             self.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
             self.step_count = int(float(st["step"]))
+            self._opt_ws.zero_()
         g = sd.get("param_groups", [{}])[0]
         self.lr = g.get("lr", self.lr)
         self.weight_decay = g.get("weight_decay", self.weight_decay)

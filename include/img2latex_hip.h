@@ -15,7 +15,10 @@
  *     every call only ENQUEUES work, it never synchronises or allocates.
  *   - workspace is caller-provided; its size comes from *_workspace_bytes().
  *   - return value: I2L_OK (0) or a negative I2L_ERR_* code; never throws,
- *     never aborts; no global state (thread-compatible).
+ *     never aborts; no global state (thread-compatible): the library reads no
+ *     environment variable and keeps nothing between calls -- where an entry
+ *     point has more than one kernel behind it, the choice is the explicit
+ *     `flags` argument (I2L_FLAG_*, 0 = automatic).
  *   - tensors are row-major with the reference's (PyTorch) shapes.
  */
 #ifndef IMG2LATEX_HIP_H
@@ -39,6 +42,16 @@ extern "C" {
 
 typedef void* i2l_stream_t;
 
+/* Kernel-selection flags (bit-or; 0 = automatic = the fastest kernel built for the shape).  Every variant computes
+ * the same function; tests run the variants against each other and callers use them to fall back. */
+#define I2L_FLAG_EXACT_FP32 0x1        /* conv / linear / training GEMMs: exact fp32 products (fp32 MFMA / VALU fmaf
+                                          chains) instead of the 3 x bf16 split on the bf16 matrix cores             */
+#define I2L_FLAG_NO_GROUP 0x2          /* beam search, training recurrences: one workgroup per image / row instead of
+                                          the grouped kernels (4 co-resident workgroups exchanging through L2)       */
+#define I2L_FLAG_RESNET_NO_RING 0x4    /* i2l_conv_bn_act_bf16_fwd: single-buffered GEMM instead of the LDS ring      */
+#define I2L_FLAG_RESNET_IM2COL_STEM 0x8 /* i2l_conv_bn_act_bf16_fwd: im2col image + GEMM instead of the fused stem    */
+#define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
+
 int i2l_version(void);
 const char* i2l_error_string(int code);
 
@@ -52,14 +65,14 @@ const char* i2l_error_string(int code);
  * Arithmetic: with argmax_out == NULL (inference) and Cin <= 3 or Cin % 16 == 0, Cout % 32/64 == 0 the products
  * run on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces (six partial
  * products, fp32 accumulation): fp32-grade results (~2^-24 relative per product), not bit-identical to an fmaf
- * chain.  Environment I2L_CONV_EXACT_FP32=1, a non-NULL argmax_out (training) and other shapes use the exact
+ * chain.  flags & I2L_FLAG_EXACT_FP32, a non-NULL argmax_out (training) and other shapes use the exact
  * fp32 kernels.  The same applies to i2l_linear_bias_act_fwd for K >= 2048. */
 size_t i2l_conv_workspace_bytes(int Cin, int Cout);   /* packed-weight scratch; 0 when none is needed */
 /* argmax_out: NULL, or (B,Cout,H/2,W/2) uint8 receiving the position 2*dy+dx of each pooling
  * window's maximum (first maximum wins, as ATen) -- what the backward pass needs. */
 int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias, float* y,
                                uint8_t* argmax_out, int B, int Cin, int H, int W, int Cout, void* workspace,
-                               size_t workspace_bytes, i2l_stream_t stream);
+                               size_t workspace_bytes, int flags, i2l_stream_t stream);
 
 /* Backward of one CNN block (autograd of encoder.py:78-95 under loss.backward(), trainer.py:337):
  * given dy (B,Cout,H/2,W/2), the block's input x, output y and pooling argmax, computes
@@ -67,7 +80,8 @@ int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const float* bias
 size_t i2l_conv_bwd_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const float* y, const uint8_t* argmax,
                                const float* dy, float* dx, float* dw, float* db, int B, int Cin, int H,
-                               int W, int Cout, void* workspace, size_t workspace_bytes, i2l_stream_t stream);
+                               int W, int Cout, void* workspace, size_t workspace_bytes, int flags,
+                               i2l_stream_t stream);
 
 /* y = act(x @ w^T + bias): nn.Flatten + nn.Linear + nn.ReLU, encoder.py:105-107,125-127
  * (also nn.Linear(Hd->V), decoder.py:90).  x (M,K)  w (N,K)  bias (N) or NULL  y (M,N).
@@ -75,13 +89,13 @@ int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const float* y, c
 size_t i2l_linear_workspace_bytes(int M, int K, int N);
 int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, float* y,
                             int M, int K, int N, int relu, void* workspace, size_t workspace_bytes,
-                            i2l_stream_t stream);
+                            int flags, i2l_stream_t stream);
 /* Backward of the above: dy (M,N) -> dx (M,K) (or NULL), dw (N,K), db (N); with relu != 0 the
  * gradient is first masked by y > 0.  Gradients are overwritten. */
 size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N);
 int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                             float* dw, float* db, int M, int K, int N, int relu, void* workspace,
-                            size_t workspace_bytes, i2l_stream_t stream);
+                            size_t workspace_bytes, int flags, i2l_stream_t stream);
 
 /* ResNet encoder building blocks (reference encoder.py:132-249: torchvision ResNet trunk at :242),
  * inference, bf16 on the matrix cores with fp32 accumulation.  Activations are NHWC bf16 (void*).
@@ -91,17 +105,19 @@ int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, cons
  * x is NHWC bf16 (B,H,W,Cin), or the NCHW fp32 image batch when x_is_nchw_f32 != 0 (the stem);
  * residual is NHWC bf16 (B,Ho,Wo,Cout) or NULL; y NHWC bf16 (B,Ho,Wo,Cout).
  * Kernel choice: K = kh*kw*Cin a multiple of 64 with NHWC bf16 input runs the ring-buffered direct-to-LDS GEMM
- * (I2L_RESNET_RING=0: the single-buffered kernel); the 7x7 / stride 2 / pad 3 / 3 -> 64 stem on fp32 images runs
- * the fused stem kernel and needs no workspace (I2L_RESNET_STEM_FUSED=0: im2col image + GEMM); every other
+ * (I2L_FLAG_RESNET_NO_RING: the single-buffered kernel); the 7x7 / stride 2 / pad 3 / 3 -> 64 stem on fp32 images runs
+ * the fused stem kernel and needs no workspace (I2L_FLAG_RESNET_IM2COL_STEM: im2col image + GEMM); every other
  * shape goes through an im2col image in the workspace.  All paths compute the same bf16 x bf16 -> fp32 sums. */
 size_t i2l_conv_bf16_packed_bytes(int Cout, int Cin, int kh, int kw);
 int i2l_conv_bn_bf16_pack(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                           const float* bn_var, float bn_eps, void* packed, size_t packed_bytes, int Cout,
                           int Cin, int kh, int kw, i2l_stream_t stream);
-size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+size_t i2l_conv_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                     int flags);
 int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const void* packed, const void* residual,
                              void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
-                             int pad, int relu, void* workspace, size_t workspace_bytes, i2l_stream_t stream);
+                             int pad, int relu, void* workspace, size_t workspace_bytes, int flags,
+                             i2l_stream_t stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) on NHWC bf16: (B,H,W,C) -> (B,(H-1)/2+1,(W-1)/2+1,C). */
 int i2l_maxpool3x3s2_bf16_fwd(const void* x, void* y, int B, int H, int W, int C, i2l_stream_t stream);
 /* nn.AdaptiveAvgPool2d(1) + Flatten: NHWC bf16 (B,H,W,C) -> fp32 (B,C). */
@@ -172,8 +188,9 @@ int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* enc, int rows
  * Kernel choice: L == 1, H == 256, V <= 512, select == I2L_SELECT_LOGITS, no state in/out, steps >= 8 run the
  * grouped kernel (4 workgroups share 4 rows and keep the weights on chip, in-launch exchanges bounded by a 3 s
  * wall-clock limit); everything else the row-per-workgroup kernel.  If a bounded wait expires (GPU heavily
- * oversubscribed) every id of the affected rows is -3 and no other output is defined; I2L_DECODE_GROUP=0 in the
- * environment disables the grouped kernel. */
+ * oversubscribed) every id of the affected rows is -3, every requested logit of those rows is NaN and no other
+ * output is defined; i2l_greedy_decode_ex with rows_per_workgroup != 0 selects the row-per-workgroup kernel,
+ * which needs no co-resident partner. */
 int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
                       const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
                       float temperature, int select, int stop, int end_id,
@@ -210,14 +227,14 @@ int i2l_sample_decode(const i2l_decoder_weights* w, const void* workspace, int r
  * Kernel choice: hidden == 256, one layer, vocab <= 512, 2 <= beam <= 6 run the grouped kernel (four workgroups
  * share 12 beam slots = 12/beam images and keep the weights on chip; per step they exchange h and, per slot, each
  * member's local top-k and (max, sum exp), from which log_softmax is assembled); other shapes, and
- * I2L_BEAM_GROUP=0 in the environment (read at every call), run one workgroup per image.  Both give the same
- * sequences; scores agree to fp32 log_softmax rounding.  If a poll of the grouped kernel times out (GPU shared
- * or oversubscribed) the affected images get len_out = -3 and no other output: call again with I2L_BEAM_GROUP=0. */
+ * flags & I2L_FLAG_NO_GROUP, run one workgroup per image.  Both give the same sequences; scores agree to fp32
+ * log_softmax rounding.  If a poll of the grouped kernel times out (GPU shared or oversubscribed) the affected
+ * images get len_out = -3 and no other output: call again with I2L_FLAG_NO_GROUP. */
 size_t i2l_beam_workspace_bytes(int images, int beam, int hidden, int layers, int steps);
 int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspace, int images, int beam,
                     int steps, int start_id, int end_id, void* beam_workspace,
                     size_t beam_workspace_bytes, int32_t* seq_out, int32_t* len_out,
-                    double* score_out, i2l_stream_t stream);
+                    double* score_out, int flags, i2l_stream_t stream);
 
 /* Additive attention, general source length S (Attention.forward, decoder.py:312-343):
  * context[b] = softmax_s(v . tanh(W [hidden[b] ; enc[b,s]] + b_a)) @ enc[b].
@@ -245,17 +262,19 @@ typedef struct i2l_decoder_grads {
  * (B,T) int32 [= formulas[:, :-1], seq2seq.py:115-120]; keeps what BPTT needs in `workspace`.
  * dropout_p: nn.Dropout p (masks from a counter-based hash of `seed`; 0 disables);
  * attention_path: 0 = decoder.py:121-143 (dropout on cat[emb,enc]), 1 = :144-193 (dropout on emb).
- * logits_out (B,T,V). */
+ * logits_out (B,T,V).  flags: I2L_FLAG_NO_GROUP (row-per-workgroup recurrences), I2L_FLAG_EXACT_FP32 (GEMMs);
+ * pass the same flags to the backward call.  If a bounded wait of the grouped recurrence expires its outputs are
+ * NaN (the loss and every gradient become NaN; i2l_grad_clip_adam_step then skips the update). */
 size_t i2l_decoder_train_workspace_bytes(int B, int T, int vocab, int embed, int hidden, int layers);
 int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* enc, const int32_t* tokens, int B, int T,
                           float dropout_p, uint64_t seed, int attention_path, void* workspace,
-                          size_t workspace_bytes, float* logits_out, i2l_stream_t stream);
+                          size_t workspace_bytes, float* logits_out, int flags, i2l_stream_t stream);
 /* Backward of the above for a given dlogits (B,T,V): fills every gradient of `grads` (overwrite)
  * and denc_out (B,E).  `workspace` must be the one the forward call filled. */
 int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t* tokens, int B, int T, float dropout_p,
                           uint64_t seed, int attention_path, void* workspace, size_t workspace_bytes,
                           const float* dlogits, const i2l_decoder_grads* grads, float* denc_out,
-                          i2l_stream_t stream);
+                          int flags, i2l_stream_t stream);
 
 /* nn.CrossEntropyLoss(ignore_index=pad, label_smoothing=eps) over `rows` = B*T rows of logits (rows,V)
  * (trainer.py:111-115,335-336).  loss_sum_and_count_out[0] = SUM over non-pad rows of the per-row loss,
@@ -270,7 +289,11 @@ int i2l_ce_label_smooth_fwd_bwd(const float* logits, const int32_t* targets, int
  * n elements (trainer.py:91-93,338-342).  grads hold the gradient of the SUM loss; count_ptr (device,
  * may be NULL = 1) is the number of non-pad target tokens the sum runs over (the GLOBAL count after the
  * data-parallel all-reduce).  step >= 1 is the optimizer step number (bias correction).
- * stats_out (device, 3 floats): total gradient norm, clip coefficient, 1/count.  max_norm <= 0: no clipping. */
+ * stats_out (device, 4 floats): total gradient norm, clip coefficient, 1/count, skipped (1.0 when the total norm
+ * was not finite -- Inf/NaN gradients, e.g. after a grouped kernel's timeout -- and the call therefore left
+ * params, exp_avg and exp_avg_sq untouched, exactly what GradScaler's skipped step does; else 0.0).
+ * max_norm <= 0: no clipping.  The workspace also carries the number of skipped calls so far (zero it once before
+ * the first call; the bias correction uses step minus that number, so `step` may simply count calls). */
 size_t i2l_optimizer_workspace_bytes(void);
 int i2l_grad_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
                             const float* count_ptr, float max_norm, float lr, float beta1, float beta2,

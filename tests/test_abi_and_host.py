@@ -28,6 +28,28 @@ def test_library_exports_every_declared_symbol():
     assert handle.i2l_linear_workspace_bytes(256, 40960, 256) > 0
 
 
+def test_library_has_no_global_switches():
+    """include/img2latex_hip.h promises "no global state": kernel selection is the explicit `flags` argument, the
+    sources read no environment variable, and the Python layer never edits os.environ."""
+    csrc = os.path.join(REPO, "hmer-img2latex_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    pkg = os.path.join(REPO, "hmer-img2latex_amd", "img2latex_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                assert "os.environ[" not in open(os.path.join(root, f)).read(), f
+    header = open(os.path.join(REPO, "include", "img2latex_hip.h")).read()
+    for name in ("I2L_FLAG_EXACT_FP32", "I2L_FLAG_NO_GROUP", "I2L_FLAG_RESNET_NO_RING", "I2L_FLAG_RESNET_IM2COL_STEM"):
+        assert name in header
+    assert (_lib.FLAG_EXACT_FP32, _lib.FLAG_NO_GROUP, _lib.FLAG_RESNET_NO_RING, _lib.FLAG_RESNET_IM2COL_STEM) == (1, 2, 4, 8)
+    # the stem's im2col variant needs its image in the workspace; the fused stem needs none (host-side size query)
+    L = _lib.lib()
+    assert L.i2l_conv_bf16_workspace_bytes(2, 64, 320, 3, 64, 7, 7, 2, 3, 0) == 256
+    assert L.i2l_conv_bf16_workspace_bytes(2, 64, 320, 3, 64, 7, 7, 2, 3, _lib.FLAG_RESNET_IM2COL_STEM) > 2 * 32 * 160 * 147 * 2
+
+
 def test_state_dict_keys_match_reference():
     cfg = synth.model_config(lstm_layers=2, attention=True, embedding_dim=32, hidden_dim=64, vocab_size=50,
                              channels=1, img_height=16, img_width=32, conv_filters=(4, 8, 16))

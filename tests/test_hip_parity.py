@@ -179,7 +179,7 @@ def test_linear_kernel_odd_shapes():
         nbytes = L.i2l_linear_workspace_bytes(M, K, N)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
         rc = L.i2l_linear_bias_act_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, K, N, relu,
-                                       ws.data_ptr(), nbytes, _lib.stream_ptr())
+                                       ws.data_ptr(), nbytes, 0, _lib.stream_ptr())
         assert rc == 0
         close(y.cpu().numpy(), want.numpy(), 1e-5)
 
@@ -202,15 +202,16 @@ def test_conv_kernel_odd_shapes():
         nbytes = L.i2l_conv_workspace_bytes(Cin, Cout)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
         rc = L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(),
-                                          y.data_ptr(), None, B, Cin, H, W, Cout, ws.data_ptr(), nbytes, _lib.stream_ptr())
+                                          y.data_ptr(), None, B, Cin, H, W, Cout, ws.data_ptr(), nbytes, 0,
+                                          _lib.stream_ptr())
         assert rc == 0
         close(y.cpu().numpy(), want.numpy(), 1e-5)
 
 
 def test_error_codes_not_exceptions():
     L = _lib.lib()
-    assert L.i2l_conv3x3_relu_pool2_fwd(None, None, None, None, None, 1, 1, 4, 4, 1, None, 0, None) == -1
-    assert L.i2l_linear_bias_act_fwd(None, None, None, None, 1, 1, 1, 0, None, 0, None) == -1
+    assert L.i2l_conv3x3_relu_pool2_fwd(None, None, None, None, None, 1, 1, 4, 4, 1, None, 0, 0, None) == -1
+    assert L.i2l_linear_bias_act_fwd(None, None, None, None, 1, 1, 1, 0, None, 0, 0, None) == -1
 
 
 def test_rows_are_independent_and_batch_tail():
@@ -247,7 +248,7 @@ def test_beam_search_vs_golden(name):
 
 
 @pytest.mark.parametrize("k", [2, 3, 4, 5, 6])
-def test_grouped_beam_matches_workgroup_per_image(k, monkeypatch):
+def test_grouped_beam_matches_workgroup_per_image(k):
     """beam_group_kernel (4 workgroups share 12 beam slots, weights on chip, per-step exchanges) against beam_kernel
     (one workgroup per image) at the primary dimensions: same sequences, scores within fp32 log-softmax rounding.
     37 images: several groups per launch and a last group with unused image slots."""
@@ -257,13 +258,12 @@ def test_grouped_beam_matches_workgroup_per_image(k, monkeypatch):
     with torch.no_grad():
         enc = m.encoder(bimgs)
         got, gs = m.beam_search_batch(enc, START, END, 48, k, return_scores=True)
-        monkeypatch.setenv("I2L_BEAM_GROUP", "0")
-        want, ws = m.beam_search_batch(enc, START, END, 48, k, return_scores=True)
+        want, ws = m.beam_search_batch(enc, START, END, 48, k, return_scores=True, flags=_lib.FLAG_NO_GROUP)
     assert got == want
     assert np.allclose(gs, ws, rtol=1e-5, atol=1e-4)
 
 
-def test_grouped_beam_small_vocabulary_and_many_groups(monkeypatch):
+def test_grouped_beam_small_vocabulary_and_many_groups():
     """Vocabulary 300 (< 512: member 2 of a group owns 44 valid columns, member 3 none, so its candidates are all
     invalid and its (max, sum exp) is (-inf, 0)); 140 images at k = 5 = 70 groups = 280 workgroups, more than the
     chip holds at once, so later groups start as earlier ones finish."""
@@ -276,8 +276,7 @@ def test_grouped_beam_small_vocabulary_and_many_groups(monkeypatch):
     with torch.no_grad():
         enc = m.encoder(imgs)
         got, gs = m.beam_search_batch(enc, START, END, 40, 5, return_scores=True)
-        monkeypatch.setenv("I2L_BEAM_GROUP", "0")
-        want, ws = m.beam_search_batch(enc, START, END, 40, 5, return_scores=True)
+        want, ws = m.beam_search_batch(enc, START, END, 40, 5, return_scores=True, flags=_lib.FLAG_NO_GROUP)
     assert got == want
     assert np.allclose(gs, ws, rtol=1e-5, atol=1e-4)
     assert max(max(s) for s in got if s) < 300
@@ -387,14 +386,24 @@ def test_bf16_conv_bn_act_vs_torch(case):
     xd = dv(x) if nchw else dv(x.permute(0, 2, 3, 1)).to(torch.bfloat16)
     rd = dv(r.permute(0, 2, 3, 1)).to(torch.bfloat16) if res else None
     y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
-    wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd)
-    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=DEV)
-    _lib.check(L.i2l_conv_bn_act_bf16_fwd(xd.data_ptr(), nchw, packed.data_ptr(), _lib.ptr(rd), y.data_ptr(), B, H, W, Cin, Cout,
-                                          k, k, s, pd, 1, ws.data_ptr(), wsb, _lib.stream_ptr()), "conv_bn_act_bf16_fwd")
-    got = y.float().cpu().permute(0, 3, 1, 2)
-    assert torch.isfinite(got).all()
-    err = (got - want).abs()
-    assert float((err - 2.0 ** -7 * want.abs()).max()) <= 2e-3, float(err.max())
+    outs = []
+    # every kernel behind the entry point: automatic choice, single-buffered GEMM, forced ring depths, im2col stem
+    variants = [0, _lib.FLAG_RESNET_NO_RING, _lib.flag_resnet_ring_depth(2), _lib.flag_resnet_ring_depth(3),
+                _lib.flag_resnet_ring_depth(4), _lib.FLAG_RESNET_IM2COL_STEM]
+    for flags in variants:
+        y.fill_(float("nan"))
+        wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd, flags)
+        ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=DEV)
+        _lib.check(L.i2l_conv_bn_act_bf16_fwd(xd.data_ptr(), nchw, packed.data_ptr(), _lib.ptr(rd), y.data_ptr(), B, H, W, Cin,
+                                              Cout, k, k, s, pd, 1, ws.data_ptr(), wsb, flags, _lib.stream_ptr()),
+                   "conv_bn_act_bf16_fwd")
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all()
+        err = (got - want).abs()
+        assert float((err - 2.0 ** -7 * want.abs()).max()) <= 2e-3, (flags, float(err.max()))
+        outs.append(got)
+    for o in outs[1:]:       # the variants differ by fp32 summation order only: at most one bf16 ulp apart
+        assert float(((o - outs[0]).abs() - 2.0 ** -7 * outs[0].abs()).max()) <= 1e-3
 
 
 @pytest.mark.parametrize("model_name,hw", [("resnet18", (32, 64)), ("resnet50", (64, 96))])

@@ -122,13 +122,13 @@ def test_conv_bwd_odd_shapes():
         nb = L.i2l_conv_workspace_bytes(Cin, Cout)
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
         assert L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), am.data_ptr(), B,
-                                            Cin, H, W, Cout, ws.data_ptr(), nb, _lib.stream_ptr()) == 0
+                                            Cin, H, W, Cout, ws.data_ptr(), nb, 0, _lib.stream_ptr()) == 0
         dx, dw, db = torch.empty_like(xd), torch.empty_like(wd), torch.empty_like(bd)
         nb2 = L.i2l_conv_bwd_workspace_bytes(B, Cin, H, W, Cout)
         ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
         assert L.i2l_conv3x3_relu_pool2_bwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), am.data_ptr(), dyd.data_ptr(),
                                             dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout,
-                                            ws2.data_ptr(), nb2, _lib.stream_ptr()) == 0
+                                            ws2.data_ptr(), nb2, 0, _lib.stream_ptr()) == 0
         rel_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, "dx")
         rel_close(dw.cpu().numpy(), w.grad.numpy(), 2e-4, "dw")
         rel_close(db.cpu().numpy(), b.grad.numpy(), 2e-4, "db")

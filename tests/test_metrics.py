@@ -41,6 +41,27 @@ def test_oracle_matches_reference_outputs():
     assert MO.masked_accuracy(logits, targets, PAD) == tuple(d["ma"].tolist())
 
 
+def test_host_bleu_finalisation_is_bit_identical_to_the_reference_formula():
+    """The float64 tail that turns the kernel's integer match counts into BLEU (host logic of the product) against
+    the oracle -- itself pinned to the reference's outputs above -- on the golden pairs and 2000 seeded random pairs,
+    n = 1..4, incl. empty / shorter-than-n / zero-match sequences: equal to the last bit."""
+    import collections
+    from img2latex_amd.training.metrics import _bleu_from_counts
+    d, preds, tgts = load()
+    rng = np.random.RandomState(7)
+    for _ in range(2000):
+        preds.append(rng.randint(0, 6, size=rng.randint(0, 30)).tolist())
+        tgts.append(rng.randint(0, 6, size=rng.randint(0, 30)).tolist())
+    for p, t in zip(preds, tgts):
+        match = []
+        for g in range(1, 5):
+            pc = collections.Counter(tuple(p[i:i + g]) for i in range(len(p) - g + 1))
+            tc = collections.Counter(tuple(t[i:i + g]) for i in range(len(t) - g + 1))
+            match.append(sum(min(c, tc[k]) for k, c in pc.items()) if min(len(p), len(t)) >= g else 0)
+        for n in (1, 2, 3, 4):
+            assert _bleu_from_counts(match, len(p), len(t), n) == MO.bleu_n_score(p, t, n)
+
+
 @pytest.mark.gpu
 def test_kernel_statistics_and_scores_vs_reference():
     from img2latex_amd.training import metrics as M
