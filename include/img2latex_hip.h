@@ -66,7 +66,12 @@ const char* i2l_error_string(int code);
  * run on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces (six partial
  * products, fp32 accumulation): fp32-grade results (~2^-24 relative per product), not bit-identical to an fmaf
  * chain.  flags & I2L_FLAG_EXACT_FP32, a non-NULL argmax_out (training) and other shapes use the exact
- * fp32 kernels.  The same applies to i2l_linear_bias_act_fwd for K >= 2048. */
+ * fp32 kernels.  The same applies to i2l_linear_bias_act_fwd for K >= 2048.
+ * Limits of the split arithmetic (tests/test_hip_parity.py::test_bf16x3_*): the error class is that of an fp32 fmaf
+ * chain, |err| <= ~2^-22 (sum |x||w| + |b|), for operands of magnitude 0 or >= 2^-110 (below that the low split
+ * pieces fall into bf16's subnormal range and the class degrades towards bf16); inputs must be finite -- a
+ * non-finite input affects only the outputs whose receptive field holds it, but their value is unspecified (NaN
+ * where the fp32 product would be +-Inf; ReLU's max may drop a NaN). */
 size_t i2l_conv_workspace_bytes(int Cin, int Cout);   /* packed-weight scratch; 0 when none is needed */
 /* argmax_out: NULL, or (B,Cout,H/2,W/2) uint8 receiving the position 2*dy+dx of each pooling
  * window's maximum (first maximum wins, as ATen) -- what the backward pass needs. */

@@ -22,6 +22,35 @@ def _has_gpu():
         return False
 
 
+# measured parity errors (max |err| per check), written at session end so that a green run leaves the margins behind:
+# gpurun_out/parity_errors.json on the GPU box (copied to profiles/ when a round's numbers are recorded)
+MEASURED = {}
+
+
+def record(name, value):
+    MEASURED[name] = max(float(value), MEASURED.get(name, 0.0))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not MEASURED:
+        return
+    import json
+    out = os.path.join(REPO, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(dict(sorted(MEASURED.items())), f, indent=1)
+    except OSError:
+        pass
+
+
+def pytest_terminal_summary(terminalreporter):
+    if MEASURED:
+        terminalreporter.write_line("measured parity errors (max |err|):")
+        for k, v in sorted(MEASURED.items()):
+            terminalreporter.write_line(f"  {k}: {v:.3e}")
+
+
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
         return
