@@ -127,6 +127,39 @@ __global__ __launch_bounds__(MT) void masked_accuracy_kernel(const float* __rest
     }
 }
 
+// One wave per row: keep the tokens before the first stop position (id == end_id, or id < 0 = the decode kernel's
+// "row already finished" filler) whose id is not in drop[0..n_drop), in order.  64 positions per pass: ballot of the
+// keep flags, rank = popcount of the lower lanes.
+__global__ __launch_bounds__(MT) void compact_ids_kernel(const int32_t* __restrict__ ids, int rows, int width, int stride,
+                                                         int end_id, const int* __restrict__ drop, int n_drop,
+                                                         int32_t* __restrict__ out, int out_stride,
+                                                         int32_t* __restrict__ out_len) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (MT / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int32_t* src = ids + (size_t)row * stride;
+    int32_t* dst = out + (size_t)row * out_stride;
+    int d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = j < n_drop ? drop[j] : -0x7fffffff;
+    int n = 0;
+    for (int base = 0; base < width; base += 64) {
+        const int pos = base + lane;
+        const int v = pos < width ? src[pos] : -1;
+        const bool stop = pos >= width || v < 0 || v == end_id;
+        const unsigned long long stops = __ballot(stop);
+        const int first_stop = stops ? __ffsll((long long)stops) - 1 : 64;
+        bool keep = lane < first_stop;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keep = keep && v != d[j];
+        const unsigned long long km = __ballot(keep);
+        if (keep) dst[n + __popcll(km & ((1ull << lane) - 1ull))] = v;
+        n += __popcll(km);
+        if (first_stop < 64) break;
+    }
+    if (lane == 0) out_len[row] = n;
+}
+
 size_t metrics_lds(int max_len) { return ((size_t)2 * max_len + 3 * ((size_t)max_len + 1) + 8) * sizeof(int); }
 
 }  // namespace
@@ -159,6 +192,17 @@ extern "C" int i2l_masked_accuracy(const float* logits, const int64_t* targets, 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(masked_accuracy_kernel, dim3((unsigned)blocks), dim3(MT), 0, s, logits, targets, (long)rows, vocab,
                        (long)pad_id, reinterpret_cast<unsigned long long*>(correct_total_out));
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+extern "C" int i2l_compact_ids(const int32_t* ids, int rows, int width, int stride, int end_id, const int32_t* drop_ids,
+                               int n_drop, int32_t* out_ids, int out_stride, int32_t* out_len, i2l_stream_t stream) {
+    if (!ids || !out_ids || !out_len || rows <= 0 || width <= 0 || stride < width || out_stride < width || n_drop < 0 ||
+        n_drop > 8 || (n_drop > 0 && !drop_ids))
+        return I2L_ERR_ARG;
+    hipLaunchKernelGGL(compact_ids_kernel, dim3(i2l_cdiv(rows, MT / 64)), dim3(MT), 0, i2l_s(stream), ids, rows, width,
+                       stride, end_id, drop_ids, n_drop, out_ids, out_stride, out_len);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }

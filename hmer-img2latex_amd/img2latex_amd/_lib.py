@@ -98,6 +98,7 @@ _SIGNATURES = {
 _SIGNATURES.update({
     "i2l_sequence_metrics": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "i2l_compact_ids": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "i2l_masked_accuracy": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     "i2l_lanczos_ksize": (c_int, [c_int, c_int]),
     "i2l_lanczos_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),

@@ -11,6 +11,7 @@ import ctypes
 import warnings
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -109,11 +110,15 @@ class Seq2SeqModel(nn.Module):
         The loop stops when ALL rows emit END in the same step (:220); the kernel runs the
         rows independently, so that step is located in the ids afterwards."""
         B = encoder_output.shape[0]
-        ids = self.greedy_ids_host(encoder_output, start_token_id, end_token_id, max_length, temperature)
-        all_end = (ids == end_token_id).all(dim=0)
-        steps = int(all_end.nonzero()[0]) + 1 if bool(all_end.any()) else max_length
-        rows = ids[:, :steps].tolist()
-        sequences = [[start_token_id] + r for r in rows]
+        ids = self.greedy_ids_host(encoder_output, start_token_id, end_token_id, max_length, temperature).numpy()
+        # host post-processing in numpy: one thread, no dispatch (torch would fan a 38 k-element compare out to every
+        # host core: measured 10 ms per batch on the 16-core GPU box against 1.4 ms for the whole device path)
+        all_end = (ids == end_token_id).all(axis=0)
+        steps = int(all_end.argmax()) + 1 if bool(all_end.any()) else max_length
+        full = np.empty((B, steps + 1), dtype=np.int64)
+        full[:, 0] = start_token_id
+        full[:, 1:] = ids[:, :steps]
+        sequences = full.tolist()
         seq = sequences[0] if B == 1 else sequences
         if B == 1:                                                # :224-231
             if seq and seq[0] == start_token_id:

@@ -128,9 +128,14 @@ def calculate_metrics(predictions: List[List[int]], targets: List[List[int]]) ->
     """metrics.py:184-223: mean BLEU-4 and mean Levenshtein similarity of a batch, one kernel launch."""
     assert len(predictions) == len(targets), "Predictions and targets must have the same length"
     num_sequences = len(predictions)
-    st = sequence_statistics(predictions, targets, 4)
+    return metrics_from_statistics(sequence_statistics(predictions, targets, 4))
+
+
+def metrics_from_statistics(st: Dict[str, torch.Tensor]) -> Dict[str, float]:
+    """The float64 tail of calculate_metrics on the kernel's integer statistics (host tensors)."""
     match, lev = st["match"].tolist(), st["lev"].tolist()
     gl, tl = st["gen_len"].tolist(), st["true_len"].tolist()
+    num_sequences = len(lev)
     bleu_scores = [_bleu_from_counts(match[i], gl[i], tl[i], 4) for i in range(num_sequences)]
     mean_bleu = sum(bleu_scores) / num_sequences
     lev_similarities = [_lev_similarity(lev[i], gl[i], tl[i]) for i in range(num_sequences)]

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Union
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -122,10 +123,68 @@ class Predictor:
             else:       # same timeout fallback as Seq2SeqModel._greedy_search
                 ids = self.model.greedy_ids_host(enc, start, end, max_length, temperature, stop=_lib.STOP_STICKY,
                                                  select=_lib.SELECT_SOFTMAX)
-        out = []
-        for row in ids.tolist():
-            row = [t for t in row if t >= 0]
-            out.append([start] + (row[: row.index(end)] if end in row else row))
+        a = ids.numpy()
+        stop = (a == end) | (a < 0)                           # first END, or the kernel's "row finished" filler
+        lens = np.where(stop.any(axis=1), stop.argmax(axis=1), a.shape[1]).tolist()
+        return [[start] + row[:n] for row, n in zip(a.tolist(), lens)]
+
+    def evaluate_batch(self, images, targets: torch.Tensor, max_length: Optional[int] = None) -> Dict:
+        """One batch of the reference's ``evaluate`` command (cli.py:449-495) with every stage on the device and
+        the token ids never leaving HBM between them:
+
+            images    a (B,C,H,W) tensor already shaped for the model, or a list of decoded uint8 arrays
+                      ((h,w) / (h,w,3)) that first go through ``preprocess_batch`` (= load_image, data/utils.py:18-90)
+            encoder -> sticky greedy loop (predictor.py:283-358) -> i2l_compact_ids (cut before END, drop the special
+            tokens: what tokenizer.decode + tokenizer.encode do to a prediction at cli.py:466-481; targets: drop PAD)
+            -> i2l_sequence_metrics -> ONE small device->host copy of the integer statistics -> the reference's
+            float64 formulas (calculate_metrics, metrics.py:184-223).
+
+        Returns {"bleu", "levenshtein", "batch_size"} as ``calculate_metrics`` does, plus "pred_ids"/"pred_len"
+        (device tensors) for callers that also want the strings."""
+        from . import metrics as M
+        L = _lib.lib()
+        tk = self.tokenizer
+        if not isinstance(images, torch.Tensor):
+            from ..data import preprocess_batch
+            enc_mod = self.model.encoder
+            images = preprocess_batch(list(images), (enc_mod.img_height, enc_mod.img_width), enc_mod.channels, True)
+        x = self._as_batch(images)
+        B = x.shape[0]
+        T = int(max_length if max_length is not None else tk.max_sequence_length)
+        tgt = targets.to(self.device, dtype=torch.int32).contiguous()
+        if tgt.dim() != 2 or tgt.shape[0] != B:
+            raise RuntimeError(f"targets must be ({B}, L) token ids, got {tuple(tgt.shape)}")
+        special = getattr(tk, "special_tokens", DEFAULT_SPECIAL_TOKENS)
+        drop = sorted({tk.token_to_id[t] for t in special.values()}) if hasattr(tk, "token_to_id") else \
+            sorted({tk.pad_token_id, tk.start_token_id, tk.end_token_id})
+        if len(drop) > 8:
+            raise NotImplementedError("img2latex_amd: at most 8 special token ids")
+        dev = x.device
+        key = (tuple(drop), tk.pad_token_id, dev)
+        if getattr(self, "_drop_key", None) != key:
+            self._drop = torch.tensor(drop, dtype=torch.int32, device=dev)
+            self._pad = torch.tensor([tk.pad_token_id], dtype=torch.int32, device=dev)
+            self._drop_key = key
+        W = max(T, tgt.shape[1])
+        p_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
+        t_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
+        p_len = torch.empty((B,), dtype=torch.int32, device=dev)
+        t_len = torch.empty((B,), dtype=torch.int32, device=dev)
+        _lib.check(L.i2l_compact_ids(tgt.data_ptr(), B, tgt.shape[1], tgt.stride(0), -1, self._pad.data_ptr(), 1,
+                                     t_ids.data_ptr(), W, t_len.data_ptr(), _lib.stream_ptr()), "compact_ids")
+        with torch.no_grad():
+            enc = self.model.encoder(x)
+            for rows_per_workgroup in (0, 1):       # 1 = the timeout fallback of Seq2SeqModel.greedy_ids_host
+                ids, _ = self.model.greedy_ids(enc, tk.start_token_id, tk.end_token_id, T, stop=_lib.STOP_STICKY,
+                                               select=_lib.SELECT_SOFTMAX, rows_per_workgroup=rows_per_workgroup)
+                _lib.check(L.i2l_compact_ids(ids.data_ptr(), B, T, ids.stride(0), int(tk.end_token_id),
+                                             self._drop.data_ptr(), len(drop), p_ids.data_ptr(), W, p_len.data_ptr(),
+                                             _lib.stream_ptr()), "compact_ids")
+                st = M.device_sequence_statistics(p_ids, p_len, t_ids, t_len, 4, tk.pad_token_id, _max_len=W)
+                if not _lib.ids_timed_out(ids[:, :1].cpu()):       # the statistics copy above already synchronised
+                    break
+        out = M.metrics_from_statistics(st)
+        out["pred_ids"], out["pred_len"] = p_ids, p_len
         return out
 
     def predict_batch(self, images, beam_size: int = 0, max_length: int = 141, temperature: float = 1.0,

@@ -324,6 +324,15 @@ int i2l_sequence_metrics(const int32_t* pred, const int32_t* pred_len, int pred_
                          const int32_t* target_len, int target_stride, int pairs, int max_len, int max_n,
                          int pad_id, int32_t* lev_out, int32_t* match_out, int32_t* tla_out, i2l_stream_t stream);
 
+/* The id post-processing between the decode loop and the metrics, on the device (cli.py:466-481 with
+ * predictor.py:350-358,384-391 and tokenizer.py:166-192): per row keep, in order, the ids BEFORE the first stop
+ * position -- id == end_id, or id < 0 (the sticky stop rule's filler) -- that are not one of drop_ids[0..n_drop)
+ * (DEVICE array of <= 8 ids: the special tokens LaTeXTokenizer.decode(skip_special_tokens=True) removes;
+ * for target rows: the PAD id, with end_id = -1 so that nothing stops a row).  ids (rows, stride) int32, `width`
+ * columns used; out_ids (rows, out_stride >= width); out_len (rows).  Bit-exact integer work. */
+int i2l_compact_ids(const int32_t* ids, int rows, int width, int stride, int end_id, const int32_t* drop_ids,
+                    int n_drop, int32_t* out_ids, int out_stride, int32_t* out_len, i2l_stream_t stream);
+
 /* masked_accuracy, metrics.py:226-238 (trainer.py:391,526): over rows = B*T logits rows of `vocab` floats,
  * correct_total_out[0] = #(argmax == target and target != pad), [1] = #(target != pad); first index wins
  * ties.  The (B,T,V) logits never leave the device (the reference copies them to the host every step). */

@@ -360,6 +360,24 @@ def adam_step(sd: SD, grads: Dict[str, torch.Tensor], state: Dict, lr: float = 1
         p.addcdiv_(m, denom, value=-lr / bc1)
 
 
+def loss_and_grads(sd: SD, cfg: Dict, images: torch.Tensor, formulas: torch.Tensor, pad_id: int = 0,
+                   dtype: torch.dtype = torch.float32):
+    """Loss and d(loss)/d(parameter) of the training forward (trainer.py:334-337), dropout off, evaluated in ``dtype``.
+    float64 gives the reference point for judging fp32 results: the pooling arg max and the ReLU boundary make the
+    conv gradients discontinuous, so two correct fp32 evaluations differ by ~1e-3 of a gradient's maximum."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        params = {k: v.detach().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        logits = seq2seq_forward(params, cfg, images.to(dtype), formulas)
+        loss = ce_label_smooth(logits, formulas[:, 1:], pad_id)
+        gl = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    finally:
+        torch.set_default_dtype(old)
+    grads = {k: (torch.zeros_like(params[k]) if g is None else g.detach()) for k, g in zip(params.keys(), gl)}
+    return float(loss.detach()), grads
+
+
 def train_step(sd: SD, cfg: Dict, images: torch.Tensor, formulas: torch.Tensor, state: Dict,
                lr: float = 1e-3, weight_decay: float = 1e-4, clip: float = 5.0,
                pad_id: int = 0) -> Dict:

@@ -32,7 +32,7 @@ def main():
         score = torch.empty((n,), dtype=torch.float64, device=dev)
         for _ in range(3):
             _lib.check(L.i2l_beam_decode(ctypes.byref(w), dec._ws.data_ptr(), n, k, T, synth.START, synth.END, bws.data_ptr(), nbytes,
-                                         seq.data_ptr(), ln.data_ptr(), score.data_ptr(), _lib.stream_ptr()), "beam")
+                                         seq.data_ptr(), ln.data_ptr(), score.data_ptr(), 0, _lib.stream_ptr()), "beam")
         torch.cuda.synchronize()
     hist = (2 * n * T * k * 4 + 255) // 256 * 256
     st = bws[hist:hist + 2048].cpu().numpy().view("uint32")

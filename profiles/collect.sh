@@ -15,4 +15,13 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p
 # matrix-pipe busy cycles (summed over all SIMDs) and the GPU-active clock count (summed over the 8 XCDs)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o p -- python bench.py --steps 3 --warmup 1 > $OUT/mfma.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_train -o p -- python bench.py --mode train --steps 3 --warmup 1 > $OUT/mfma_train.log 2>&1
-find $OUT -name "*.csv" | head -20
+# the secondary configs (BASELINE configs[2..4]): bench lines with their own roofline / cpu_baseline, per-kernel stats,
+# matrix-pipe counters of the ResNet trunk
+for m in beam train resnet preprocess metrics; do
+  python bench.py --mode $m --steps 20 --warmup 3 > $OUT/bench_$m.json 2> $OUT/bench_$m.err
+done
+for m in beam train resnet; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$m -o p -- python bench.py --mode $m --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_$m.log 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_resnet -o p -- python bench.py --mode resnet --steps 3 --warmup 1 --no-cpu-baseline > $OUT/mfma_resnet.log 2>&1
+find $OUT -name "*.csv" | head -40

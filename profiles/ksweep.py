@@ -12,10 +12,10 @@ def run_case(B, H, W, Cin, Cout, k, s, pd, res=0, n=30):
     packed = torch.empty(nb, dtype=torch.uint8, device=dev)
     _lib.check(L.i2l_conv_bn_bf16_pack(w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), ones.data_ptr(), 1e-5, packed.data_ptr(), nb, Cout, Cin, k, k, _lib.stream_ptr()), "pack")
     y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
-    wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd)
+    wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd, 0)
     ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
     def run():
-        _lib.check(L.i2l_conv_bn_act_bf16_fwd(x.data_ptr(), 0, packed.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout, k, k, s, pd, 1, ws.data_ptr(), wsb, _lib.stream_ptr()), "conv")
+        _lib.check(L.i2l_conv_bn_act_bf16_fwd(x.data_ptr(), 0, packed.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout, k, k, s, pd, 1, ws.data_ptr(), wsb, 0, _lib.stream_ptr()), "conv")
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

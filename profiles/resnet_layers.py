@@ -1,7 +1,7 @@
 """Per-layer timing of the bf16 ResNet-50 convolutions at the bench shape (B=256, 3x64x320).
 
     python profiles/resnet_layers.py            # ring-buffered GEMM (default)
-    I2L_RESNET_RING=0 python profiles/resnet_layers.py   # single-buffered kernel
+    FLAGS=4 python profiles/resnet_layers.py    # I2L_FLAG_RESNET_NO_RING: single-buffered kernel (FLAGS = I2L_FLAG_* bits)
 
 Prints microseconds, TFLOP/s and the algorithmic GB/s (input + weights + residual + output, each once)."""
 import os
@@ -31,6 +31,7 @@ LAYERS = [
 
 def main():
     B = int(os.environ.get("B", "256"))
+    FLAGS = int(os.environ.get("FLAGS", "0"))      # script-level switch, passed to the ABI as an explicit argument
     L = _lib.lib()
     dev = torch.device("cuda:0")
     total = 0.0
@@ -45,12 +46,12 @@ def main():
                                            1e-5, packed.data_ptr(), nb, Cout, Cin, k, k, _lib.stream_ptr()), "pack")
         r = (torch.randn(B, Ho, Wo, Cout, device=dev)).to(torch.bfloat16) if res else None
         y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
-        wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd)
+        wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd, FLAGS)
         ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
 
         def run():
             _lib.check(L.i2l_conv_bn_act_bf16_fwd(x.data_ptr(), 0, packed.data_ptr(), _lib.ptr(r), y.data_ptr(), B, H, W, Cin, Cout,
-                                                  k, k, s, pd, 1, ws.data_ptr(), wsb, _lib.stream_ptr()), "conv")
+                                                  k, k, s, pd, 1, ws.data_ptr(), wsb, FLAGS, _lib.stream_ptr()), "conv")
         for _ in range(3):
             run()
         torch.cuda.synchronize()

@@ -27,13 +27,13 @@ def main():
         _lib.check(L.i2l_conv_bn_bf16_pack(w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), ones.data_ptr(), 1e-5,
                                            packed.data_ptr(), nb, Cout, Cin, k, k, _lib.stream_ptr()), "pack")
         r = torch.randn(B, Ho, Wo, Cout, generator=g).to(torch.bfloat16).to(dev) if res else None
-        wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd)
+        wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd, 0)
         ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
         ref = None
         for rep in range(30):
             y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
             _lib.check(L.i2l_conv_bn_act_bf16_fwd(x.data_ptr(), 0, packed.data_ptr(), _lib.ptr(r), y.data_ptr(), B, H, W, Cin, Cout,
-                                                  k, k, s, pd, 1, ws.data_ptr(), wsb, _lib.stream_ptr()), "conv")
+                                                  k, k, s, pd, 1, ws.data_ptr(), wsb, 0, _lib.stream_ptr()), "conv")
             yi = y.view(torch.int16)
             if ref is None:
                 ref = yi.clone()

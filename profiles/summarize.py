@@ -78,5 +78,18 @@ def mfma_table(sub, dst_name):
 
 mfma_table("mfma", f"pmc_mfma_busy_{tag}.csv")
 mfma_table("mfma_train", f"pmc_mfma_busy_train_{tag}.csv")
+mfma_table("mfma_resnet", f"pmc_mfma_busy_resnet_{tag}.csv")
+# secondary configs: bench lines (one JSON line per mode) and per-kernel stats
+lines = [open(f"{src}/bench.json").read().strip()]
+for m in ("beam", "train", "resnet", "preprocess", "metrics"):
+    if os.path.exists(f"{src}/bench_{m}.json"):
+        lines.append(open(f"{src}/bench_{m}.json").read().strip())
+    st = f"{src}/stats_{m}/p_kernel_stats.csv"
+    if os.path.exists(st):
+        shutil.copy(st, f"{dst}/{m}_{tag}_kernel_stats.csv")
+with open(f"{dst}/bench_all_modes_{tag}.jsonl", "w") as f:
+    f.write("\n".join(l for l in lines if l) + "\n")
+if os.path.exists("gpurun_out/parity_errors.json"):
+    shutil.copy("gpurun_out/parity_errors.json", f"{dst}/parity_errors_{tag}.json")
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_") and k != "raw_kb"}, indent=1))
