@@ -15,6 +15,14 @@
 // The recurrent product h . Whh^T of the NEXT step does not depend on the token (only the table row P[token] that is
 // added at its end does), so it runs between publishing the candidates and polling for them: exchange 2 is hidden.
 //
+// Synchronisation inside a workgroup is ONE barrier per step (after the h exchange).  The two others of the first
+// design are gone: (i) every WAVE polls the 16 candidate granules of the previous step itself (its own member's too:
+// they are published to L2 like the peers'), merges them in registers and -- because it needs nobody's permission --
+// does so in the middle of the recurrent product, so that the gather of the token's table row P[token] is in flight
+// while the rest of that product runs; (ii) the per-row arg max over the eight waves is an LDS 64-bit atomic max, and
+// the wave that arrives last (an LDS counter tells it) publishes the member's four candidates.  h lives in two LDS
+// buffers by step parity, which is what makes the remaining barrier sufficient.
+//
 // Exchange = 8-byte {value, tag} granules, tag = step + 1, each written by ONE agent-scope relaxed atomic store (sc1,
 // write-through) and polled by agent-scope relaxed atomic loads (sc1: never served from this CU's L1 or a stale L2
 // line): the data is its own flag, no fences, no dependence on XCD placement.  Two buffers by step parity suffice:
@@ -34,7 +42,9 @@ constexpr int GRAN_H = 256;              // h granules per member and step: [uni
 constexpr int GRAN_C = GRAN_H;           // 4 candidate granules (one per row), a 128-byte line of their own
 constexpr int GRAN_X = GRAN_H + 16;      // 1 placement granule (XCC id), a line of its own
 constexpr int GRAN = GRAN_H + 32;
-constexpr size_t GRP_LDS = (size_t)(256 * 128 + 256 * 4) * sizeof(float) + (size_t)2 * 4 * 32 * 8 + 8 * sizeof(int);
+// LDS: W_out quarter | h [2 parities][256 k][4 rows] | per-thread image-side gate constants (Genc, read once per step: four
+// registers less across the recurrent product) | arg-max keys [2 parities][4 rows] | arrival counters [2] + flags
+constexpr size_t GRP_LDS = (size_t)(256 * 128 + 2 * 256 * 4 + GNT * 4) * sizeof(float) + (size_t)2 * 4 * 8 + 8 * sizeof(int);
 
 struct GroupParams {
     StepWeights w;
@@ -49,12 +59,16 @@ struct GroupParams {
     unsigned* status;     // [0] != 0: a poll timed out
 };
 
+constexpr int DPP_SHL12 = 0x10C;
+
 __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* wout_s4 = reinterpret_cast<float4*>(smem);      // [16 j][512 threads]: WoutT[16j + ks][128m + 4cq ..+3]
-    float* h_s = smem + 256 * 128;                          // [256 k][4 rows]  full h of the last step
-    u64_t* redk = reinterpret_cast<u64_t*>(h_s + 256 * 4);  // [2][4 rows][32 column groups] arg-max keys
-    int* tok_s = reinterpret_cast<int*>(redk + 2 * 4 * 32); // [0..3] tokens of the last step (-1: timed out), [4] h poll timed out
+    float* h_s = smem + 256 * 128;                          // [2][256 k][4 rows]  full h of step t in buffer t & 1
+    float4* genc_s = reinterpret_cast<float4*>(h_s + 2 * 256 * 4);   // [512 threads] Genc[row ke & 3][4 unit ..+3]
+    u64_t* redk = reinterpret_cast<u64_t*>(genc_s + GNT);   // [2][4 rows] arg-max keys of this member's columns
+    int* cnt_s = reinterpret_cast<int*>(redk + 2 * 4);      // [0..1] waves that added their keys (by parity),
+                                                            // [2] a poll timed out, [3] members share one XCD
 
     const StepWeights& w = p.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,25 +96,24 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         wout_s4[j * GNT + tid] = *reinterpret_cast<const float4*>(w.WoutT + (size_t)(16 * j + ks) * 512 + 128 * m + 4 * cq);
-    for (int idx = tid; idx < 256 * 4; idx += GNT) h_s[idx] = 0.f;
-    const float4 genc = *reinterpret_cast<const float4*>(w.Genc + (size_t)min(row0 + (ke & 3), B - 1) * G + 4 * unit);
+    for (int idx = tid; idx < 2 * 256 * 4; idx += GNT) h_s[idx] = 0.f;
+    if (tid < 8) redk[tid] = 0;
+    if (tid < 4) cnt_s[tid] = 0;
+    genc_s[tid] = *reinterpret_cast<const float4*>(w.Genc + (size_t)min(row0 + (ke & 3), B - 1) * G + 4 * unit);
     const float l_bias = w.boutP[l_v];
     float c_own = 0.f, h_own = 0.f;
-    int tok[GQ];
     unsigned fin = 0;                                       // bit r: row r has emitted END (or does not exist)
 #pragma unroll
-    for (int r = 0; r < GQ; ++r) {
-        tok[r] = min(max(p.tok0[min(row0 + r, B - 1)], 0), V - 1);
+    for (int r = 0; r < GQ; ++r)
         if (row0 + r >= B) fin |= 1u << r;
-    }
     u64_t* xg = p.xchg + (size_t)group * 2 * GQ * GRAN;
     const bool own_row = row0 + m < B;                      // this member writes the ids of row m
     int32_t* ids_row = (p.ids && own_row) ? p.ids + (size_t)(row0 + m) * T : nullptr;
     float* lrow = (p.logits && row0 + l_row < B && l_v < V) ? p.logits + (size_t)(row0 + l_row) * T * V + l_v : nullptr;
-    u64_t cand_k = 0;                                       // wave 0, lanes 0..3: this member's candidate of row = lane
     // Placement: are the four members on one XCD?  Each publishes its XCC id (sc1, seen from anywhere); equal ids
     // switch the granule stores to the L2-local flavour.  Measured, never assumed: correctness does not depend on it
     // (if a member times out here it fails the launch like any other poll).
+    __syncthreads();                                        // the LDS initialisation above
     if (wave == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -123,13 +136,19 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
             }
         }
         const bool all_same = __all(lane >= 3 || (unsigned)pv == xcc);
-        if (lane == 0) { tok_s[5] = (all_same && !bad) ? 1 : 0; tok_s[4] = bad ? 1 : 0; }
+        if (lane == 0) { cnt_s[3] = (all_same && !bad) ? 1 : 0; if (bad) cnt_s[2] = 1; }
     }
     __syncthreads();
-    const bool local = tok_s[5] != 0;
+    const bool local = cnt_s[3] != 0;
+
+    // token of the row this lane's cell belongs to (row ke & 3) and its table row, gathered as early as the token is known
+    const int my_r = ke & 3;
+    int mytok = min(max(p.tok0[min(row0 + my_r, B - 1)], 0), V - 1);
+    if (p.forced) mytok = min(max(p.forced[(size_t)min(row0 + my_r, B - 1) * T], 0), V - 1);
+    float4 pvec = *reinterpret_cast<const float4*>(w.P + (size_t)mytok * G + 4 * unit);
 
     int t = 0;
-    bool failed = false;
+    bool failed = cnt_s[2] != 0;
 #ifdef I2L_GROUP_STAMPS
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long st_last = (long long)wall_clock64();
@@ -137,19 +156,48 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
 #else
 #define I2L_STAMP(i) do { } while (0)
 #endif
-    for (;; ++t) {
-        // ---- A. token-independent part of the gates of step t: sum_k h[k] Whh[k][.]
+    for (; !failed; ++t) {
+        // ---- A. token-independent part of the gates of step t: sum_k h(t-1)[k] Whh[k][.]; on the way, the tokens chosen
+        //         at step t-1: every wave polls the 16 candidate granules {member q, row r} = lane 4q + r itself
         f32x2 acc[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) { acc[g][0] = splat2(0.f); acc[g][1] = splat2(0.f); }
-        u64_t gv = 0;                                       // wave 0, lanes 0..11: candidate granule (peer, row)
-        const int c_qi = lane >> 2;
-        const u64_t* cand_src = xg + (size_t)((t - 1) & 1) * GQ * GRAN + (size_t)(c_qi + (c_qi >= m ? 1 : 0)) * GRAN +
-                                GRAN_C + (lane & 3);
-        const bool c_poll = wave == 0 && lane < 12 && t > 0;
+        const float* hprev = h_s + ((t - 1) & 1) * 1024;
+        const u64_t* cand_src = xg + (size_t)((t - 1) & 1) * GQ * GRAN + (size_t)((lane >> 2) & 3) * GRAN + GRAN_C + (lane & 3);
+        const unsigned c_epoch = (unsigned)t;               // candidates of step t-1 carry tag t
+        bool have = t == 0;                                 // tokens of step t-1 known (wave-uniform)
+        int tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        // The poll is split in two so that the L2 round trip of the sc1 loads hides behind the product: issue() sends the
+        // 16 loads, check() -- three k batches later -- looks at what came back: all 16 granules there -> merge (members
+        // own disjoint index ranges: any order), broadcast the four tokens, start the gather of this lane's table row.
+        u64_t gv = 0;
+        auto issue = [&]() {
+            if (lane < 16) gv = load_granule(cand_src);
+        };
+        auto check = [&]() {
+            if (!__all(lane >= 16 || (unsigned)(gv >> 48) == c_epoch)) return;
+            const int g_lo = (int)(unsigned)gv, g_hi = (int)(unsigned)(gv >> 32);
+            u64_t best = am_key(__int_as_float(g_lo), g_hi & 0xFFFF);
+            best = umax64(best, am_key(__int_as_float(__builtin_amdgcn_mov_dpp(g_lo, DPP_SHL4, 0xF, 0xF, true)),
+                                       __builtin_amdgcn_mov_dpp(g_hi, DPP_SHL4, 0xF, 0xF, true) & 0xFFFF));
+            best = umax64(best, am_key(__int_as_float(__builtin_amdgcn_mov_dpp(g_lo, DPP_SHL8, 0xF, 0xF, true)),
+                                       __builtin_amdgcn_mov_dpp(g_hi, DPP_SHL8, 0xF, 0xF, true) & 0xFFFF));
+            best = umax64(best, am_key(__int_as_float(__builtin_amdgcn_mov_dpp(g_lo, DPP_SHL12, 0xF, 0xF, true)),
+                                       __builtin_amdgcn_mov_dpp(g_hi, DPP_SHL12, 0xF, 0xF, true) & 0xFFFF));
+            const int bi = am_idx(best);                    // lanes 0..3: the token of row = lane
+            tk0 = __builtin_amdgcn_readlane(bi, 0); tk1 = __builtin_amdgcn_readlane(bi, 1);
+            tk2 = __builtin_amdgcn_readlane(bi, 2); tk3 = __builtin_amdgcn_readlane(bi, 3);
+            tk0 = tk0 < V ? tk0 : 0; tk1 = tk1 < V ? tk1 : 0; tk2 = tk2 < V ? tk2 : 0; tk3 = tk3 < V ? tk3 : 0;
+            have = true;
+            if (t < T) {
+                mytok = my_r == 0 ? tk0 : (my_r == 1 ? tk1 : (my_r == 2 ? tk2 : tk3));
+                if (p.forced) mytok = min(max(p.forced[(size_t)min(row0 + my_r, B - 1) * T + t], 0), V - 1);
+                pvec = *reinterpret_cast<const float4*>(w.P + (size_t)mytok * G + 4 * unit);
+            }
+        };
         if (t > 0 && t < T) {
             // h is read 4 k ahead of its use (two register sets)
-            const float4* hq4 = reinterpret_cast<const float4*>(h_s) + ke;
+            const float4* hq4 = reinterpret_cast<const float4*>(hprev) + ke;
             float4 hb[2][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) hb[0][i] = hq4[8 * i];
@@ -159,73 +207,53 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hb[(b + 1) & 1][i] = hq4[8 * ((b + 1) * 4 + i)];
                 }
-                // the peers published their candidates about when this member did: fetch them mid-way, use them after
-                if (b == 4 && c_poll) gv = load_granule(cand_src);
+                // the peers published their candidates about when this member did: ask early, look three batches later
+                if (b == 1) issue();
+                if (b == 4) { check(); if (!have) issue(); }
+                if (b == 7 && !have) check();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fma_4x4(acc, wreg[b * 4 + i][0], wreg[b * 4 + i][1], hb[b & 1][i]);
             }
-        } else if (c_poll) {
-            gv = load_granule(cand_src);
         }
         I2L_STAMP(0);
-        // ---- B. tokens chosen at step t-1: combine the four members' candidates (wave 0), tell the workgroup
-        if (t > 0) {
-            const unsigned epoch = (unsigned)t;             // candidates of step t-1 carry tag t
-            if (wave == 0) {
-                bool bad = false;
-                long long t_start = 0;
-                unsigned spins = 0;
-                for (;;) {
-                    const bool ok = lane >= 12 || (unsigned)(gv >> 48) == epoch;
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 255u) == 0) {
-                        const long long now = (long long)wall_clock64();
-                        if (t_start == 0) t_start = now;
-                        else if (now - t_start > GRP_TIMEOUT_TICKS) { bad = true; break; }
-                    }
-                    if (lane < 12) gv = load_granule(cand_src);
+        // ---- B. wait for the tokens if they are not there yet
+        if (!have) {
+            long long t_start = 0;
+            unsigned spins = 0;
+            for (;;) {
+                issue();
+                check();
+                if (have) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255u) == 0) {
+                    const long long now = (long long)wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
                 }
-                // lane r < 4 gathers the three peers' granules of row r (lanes r, r+4, r+8); the members own disjoint
-                // index ranges, so the order of the max does not matter
-                const int g_lo = (int)(unsigned)gv, g_hi = (int)(unsigned)(gv >> 32);
-                u64_t best = umax64(cand_k, am_key(__int_as_float(g_lo), g_hi & 0xFFFF));
-                best = umax64(best, am_key(__int_as_float(__builtin_amdgcn_mov_dpp(g_lo, DPP_SHL4, 0xF, 0xF, true)),
-                                           __builtin_amdgcn_mov_dpp(g_hi, DPP_SHL4, 0xF, 0xF, true) & 0xFFFF));
-                best = umax64(best, am_key(__int_as_float(__builtin_amdgcn_mov_dpp(g_lo, DPP_SHL8, 0xF, 0xF, true)),
-                                           __builtin_amdgcn_mov_dpp(g_hi, DPP_SHL8, 0xF, 0xF, true) & 0xFFFF));
-                if (lane < 4) tok_s[lane] = bad ? -1 : am_idx(best);
             }
-            __syncthreads();
-            const int4 tk4 = *reinterpret_cast<const int4*>(tok_s);
-            const int4 fl4 = *reinterpret_cast<const int4*>(tok_s + 4);
-            if (tk4.x < 0 || fl4.x != 0) { failed = true; break; }
-            const int tk[4] = {tk4.x, tk4.y, tk4.z, tk4.w};
+            if (failed) { cnt_s[2] = 1; break; }
+        }
+        if (t > 0) {
+            const int tk[4] = {tk0, tk1, tk2, tk3};
             bool all_fin = true;
 #pragma unroll
             for (int r = 0; r < GQ; ++r) {
-                const int sel = tk[r] < V ? tk[r] : 0;
                 const bool was_fin = (fin >> r) & 1u;
-                if (r == m && tid == 0 && ids_row) ids_row[t - 1] = (p.stop == I2L_STOP_STICKY && was_fin) ? -1 : sel;
-                tok[r] = sel;
-                if (sel == p.end_id) fin |= 1u << r;
+                if (r == m && tid == 0 && ids_row) ids_row[t - 1] = (p.stop == I2L_STOP_STICKY && was_fin) ? -1 : tk[r];
+                if (tk[r] == p.end_id) fin |= 1u << r;
                 all_fin = all_fin && ((fin >> r) & 1u);
             }
             if (t == T || (p.stop == I2L_STOP_STICKY && all_fin)) break;
         }
         I2L_STAMP(1);
-        if (p.forced) {
-#pragma unroll
-            for (int r = 0; r < GQ; ++r) tok[r] = min(max(p.forced[(size_t)min(row0 + r, B - 1) * T + t], 0), V - 1);
-        }
         // ---- C. fold the 8 k-slices (reduce-scatter: 16 -> 8 -> 4 -> 2 values per lane), LSTM cell of (unit, row ke)
         const unsigned epoch = (unsigned)t + 1u;
-        u64_t* slot = xg + (size_t)(t & 1) * GQ * GRAN;
+        const int par = t & 1;
+        u64_t* slot = xg + (size_t)par * GQ * GRAN;
+        float* hcur = h_s + par * 1024;
         {
-            const int kr = ke & 3;
-            const int mytok = kr == 0 ? tok[0] : (kr == 1 ? tok[1] : (kr == 2 ? tok[2] : tok[3]));
-            const float4 pv = *reinterpret_cast<const float4*>(w.P + (size_t)mytok * G + 4 * unit);
+            const float4 genc = genc_s[tid];
             const bool b0 = ke & 1, b1 = ke & 2, b2 = ke & 4;
             float z[2];                                     // lanes ke < 4: gates (i, f); ke >= 4: (g, o); row ke & 3
 #pragma unroll
@@ -240,17 +268,20 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
                 z[e] = rs_level<DPP_XOR2>(wv[0], wv[1], b1);
             }
             const float g2 = dpp_f<DPP_SHL4>(z[0]), g3 = dpp_f<DPP_SHL4>(z[1]);      // (g, o) from lane ke + 4
-            const float xi = (z[0] + genc.x) + pv.x, xf = (z[1] + genc.y) + pv.y;
-            const float xc = (g2 + genc.z) + pv.z, xo = (g3 + genc.w) + pv.w;
+            const float xi = (z[0] + genc.x) + pvec.x, xf = (z[1] + genc.y) + pvec.y;
+            const float xc = (g2 + genc.z) + pvec.z, xo = (g3 + genc.w) + pvec.w;
             const float ig = sigmoidf_(xi), fg = sigmoidf_(xf), gg = tanhf(xc), og = sigmoidf_(xo);
             c_own = fg * c_own + ig * gg;
             h_own = og * tanhf(c_own);
         }
-        if (ke < 4) store_granule(slot + (size_t)m * GRAN + ul * 4 + ke, granule(epoch, h_own), local);
+        if (ke < 4) {
+            store_granule(slot + (size_t)m * GRAN + ul * 4 + ke, granule(epoch, h_own), local);
+            hcur[m * 256 + ul * 4 + ke] = h_own;
+        }
         I2L_STAMP(2);
         // ---- D. the other three quarters of h: threads 0..255 fetch peers 0 and 1, threads 256..511 peer 2
-        u64_t gr[2];
         {
+            u64_t gr[2];
             const int gi = tid & 255;
             const int qa = tid < 256 ? 0 : 2;
             const u64_t* pa_ = slot + (size_t)(qa + (qa >= m ? 1 : 0)) * GRAN + gi;
@@ -265,17 +296,15 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
                 if ((++spins & 255u) == 0) {
                     const long long now = (long long)wall_clock64();
                     if (t_start == 0) t_start = now;
-                    else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
+                    else if (now - t_start > GRP_TIMEOUT_TICKS) { cnt_s[2] = 1; break; }
                 }
             }
             I2L_STAMP(3);
-            // every thread passed the barrier of B (t > 0) after its reads of h_s, so h_s may be rewritten right away
-            h_s[(qa + (qa >= m ? 1 : 0)) * 256 + gi] = __uint_as_float((unsigned)gr[0]);
-            if (tid < 256) h_s[(1 + (1 >= m ? 1 : 0)) * 256 + gi] = __uint_as_float((unsigned)gr[1]);
+            hcur[(qa + (qa >= m ? 1 : 0)) * 256 + gi] = __uint_as_float((unsigned)gr[0]);
+            if (tid < 256) hcur[(1 + (1 >= m ? 1 : 0)) * 256 + gi] = __uint_as_float((unsigned)gr[1]);
         }
-        if (ke < 4) h_s[m * 256 + ul * 4 + ke] = h_own;
-        if (failed) { tok_s[4] = 1; failed = false; }      // a timed-out poll is reported at the next B (all threads see it)
-        __syncthreads();
+        __syncthreads();                                    // THE barrier of the step: h(t) complete in hcur
+        if (cnt_s[2] != 0) { failed = true; break; }        // some wave's poll timed out: everybody leaves here
         I2L_STAMP(4);
 
         // ---- E. logits of this member's 128 columns: thread = (4 columns, k = ks mod 16), 4 rows -> 16 sums
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { pa[c][0] = splat2(0.f); pa[c][1] = splat2(0.f); }
         {
-            const float4* hq4 = reinterpret_cast<const float4*>(h_s) + ks;
+            const float4* hq4 = reinterpret_cast<const float4*>(hcur) + ks;
             float4 wb[2][2], hb[2][2];
             auto fetch = [&](int set, int b) {
 #pragma unroll
@@ -328,22 +357,20 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
         u64_t key = am_key(lv, l_v);
         key = umax64(key, dpp_u64<DPP_ROR4>(key));          // the 4 lanes of a 16-lane row that share the row (lane & 3)
         key = umax64(key, dpp_u64<DPP_ROR8>(key));
-        const int par = (t & 1) * 128;
-        if (ks < 4) redk[par + ks * 32 + cq] = key;
-        __syncthreads();
-        if (wave == 0) {
-            // lanes 0..15: row lane & 3, keys [8 (lane >> 2), +8) of its 32; then the 4 lanes of a row fold
-            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(redk + par + (lane & 3) * 32 + ((lane >> 2) & 3) * 8);
-            u64_t best = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const ulonglong2 k2 = src[j]; best = umax64(best, umax64(k2.x, k2.y)); }
-            best = umax64(best, dpp_u64<DPP_ROR4>(best));
-            best = umax64(best, dpp_u64<DPP_ROR8>(best));
+        // ---- F. arg max of the member's 128 columns per row: LDS atomic max of the 16 (row, column quad) keys of the
+        //         wave; the wave that adds last publishes the four candidates and clears the other parity for step t+1
+        if (ks < 4) atomicMax(reinterpret_cast<unsigned long long*>(redk + par * 4 + ks), (unsigned long long)key);
+        int arrived = 0;
+        if (lane == 0) arrived = atomicAdd(cnt_s + par, 1);   // LDS operations of a wave execute in order
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived == GNT / 64 - 1) {
             if (lane < 4) {
-                cand_k = best;
+                const u64_t best = redk[par * 4 + lane];
                 store_granule(slot + (size_t)m * GRAN + GRAN_C + lane,
                               granule((epoch << 16) | (unsigned)(am_idx(best) & 0xFFFF), am_val(best)), local);
+                redk[(par ^ 1) * 4 + lane] = 0;
             }
+            if (lane == 0) cnt_s[par ^ 1] = 0;
         }
         I2L_STAMP(6);
     }
@@ -353,7 +380,7 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
     if (failed) {
         // loud failure: ids -3 (checked by the host wrappers) and NaN logits (a caller that asked for logits only --
         // the validation forward -- gets a NaN loss instead of a partly written tensor)
-        if (tid == 0) atomicOr(p.status, 1u);
+        if (lane == 0) atomicOr(p.status, 1u);
         if (ids_row) for (int tt = tid; tt < T; tt += GNT) ids_row[tt] = -3;
         if (lrow) for (int tt = 0; tt < T; ++tt) lrow[(size_t)tt * V] = __builtin_nanf("");
         return;
