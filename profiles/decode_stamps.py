@@ -1,6 +1,7 @@
 import ctypes, sys, torch
 sys.path.insert(0, "hmer-img2latex_amd")
 from img2latex_amd import synth, _lib
+_lib.LIB_PATH = "hmer-img2latex_amd/csrc/build/libimg2latex_hip_stamps.so"      # built by profiles/run_stamps.sh
 from img2latex_amd.model import Seq2SeqModel
 cfg = synth.model_config()
 dev = torch.device("cuda:0")
