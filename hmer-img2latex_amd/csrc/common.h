@@ -57,5 +57,5 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
 // (full != 0: plain full-resolution conv with the flipped / transposed filter = a block's data gradient; H, W even)
 // first conv block (Cin <= 3): whole K in one or two bf16 k-steps, filters in registers, im2col image in LDS
 bool i2l_conv_smallk_applicable(int Cin, int Cout);
-int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
-                        hipStream_t s);
+int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
+                        int H, int W, int Cout, hipStream_t s);

@@ -466,11 +466,18 @@ extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const 
                                            i2l_stream_t stream) {
     if (!x || !w || !bias || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2) return I2L_ERR_ARG;
     const bool exact = (flags & I2L_FLAG_EXACT_FP32) != 0;
-    // inference forward (no argmax wanted): split-bf16 matrix-core kernel where the channel counts allow
-    if (!exact && !argmax_out && i2l_conv_smallk_applicable(Cin, Cout))
-        return i2l_conv_smallk_run(x, w, bias, y, B, Cin, H, W, Cout, i2l_s(stream));
-    if (!exact && !argmax_out && i2l_conv_bf16x3_applicable(Cin, Cout))
-        return i2l_conv_bf16x3_run(x, w, bias, y, nullptr, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
+    // split-bf16 matrix-core kernels where the channel counts allow: always for inference; for the training forward
+    // (argmax_out != NULL) only on request.  The conv gradients are non-smooth in the forward values (ReLU boundary,
+    // pooling arg max) and their sums cancel to ~1e-3 of their terms, so a forward pass that differs from ATen's by
+    // 5e-7 instead of 1e-7 moves individual gradient elements by up to ~4e-3 of the gradient's maximum -- the same
+    // distance the fp32 reference itself keeps from a float64 evaluation, but enough to miss the reference-generated
+    // post-Adam fixture (G6) by 4e-6 on one sample in 120 (tests/test_hip_training.py records both).  Parity first:
+    // the default training forward stays on the exact-fp32 kernels, 0.11 ms per 64-image step slower.
+    const bool split = !exact && (!argmax_out || (flags & I2L_FLAG_TRAIN_FWD_SPLIT));
+    if (split && i2l_conv_smallk_applicable(Cin, Cout))
+        return i2l_conv_smallk_run(x, w, bias, y, argmax_out, B, Cin, H, W, Cout, i2l_s(stream));
+    if (split && i2l_conv_bf16x3_applicable(Cin, Cout))
+        return i2l_conv_bf16x3_run(x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
     return run_conv(true, x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream), exact);
 }
 

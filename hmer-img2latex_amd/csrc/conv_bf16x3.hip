@@ -93,7 +93,8 @@ __global__ void conv_pack3_kernel(const float* __restrict__ w, bf16_t* __restric
 }
 
 // FULL: plain full-resolution convolution (no bias / ReLU / pooling): the data gradient of a block, y is (B,Cout,H,W)
-template <int WX, bool FULL = false>
+// AM: also write the pooling arg max (training forward); a template parameter so that the inference kernel is unchanged
+template <int WX, bool FULL = false, bool AM = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wpack, const float* __restrict__ bias,
     float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     __shared__ __attribute__((aligned(16))) uint4 in_s[TL::IN_U4];
     __shared__ __attribute__((aligned(16))) uint4 w_s[W_PHASE_U4];             // the 3 taps of one filter row
     __shared__ float out_s[CO_BLK * 65];                                       // fp32 staging of the pooled tile
+    __shared__ unsigned char am_s[AM ? CO_BLK * 68 : 4];                       // pooling arg max of the tile (training)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave / WX, wx = wave % WX;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
             }
             continue;
         }
-        if (amax == nullptr && (Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
+        if ((Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
             // out_s was last read before the first barrier of this tile's first phase: free to overwrite
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -285,9 +287,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
-                                              fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
-                        out_s[(n * 32 + i) * 65 + (wy * 2 + m) * PC + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
+                        const int pos = (wy * 2 + m) * PC + wx * 8 + 2 * q + h;
+                        if constexpr (AM) {                  // training forward: first maximum wins, as ATen's max_pool2d
+                            float best = acc[m][n][4 * q];
+                            int bi = 0;
+#pragma unroll
+                            for (int e = 1; e < 4; ++e)
+                                if (acc[m][n][4 * q + e] > best) { best = acc[m][n][4 * q + e]; bi = e; }
+                            out_s[(n * 32 + i) * 65 + pos] = fmaxf(best + bv, 0.f);
+                            am_s[(n * 32 + i) * 68 + pos] = (unsigned char)bi;
+                        } else {
+                            const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
+                                                  fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
+                            out_s[(n * 32 + i) * 65 + pos] = fmaxf(v, 0.f);
+                        }
                     }
             }
             __syncthreads();
@@ -295,8 +308,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                 constexpr int XG = PC / 4;
                 const int x4 = idx % XG, py = (idx / XG) % PR, co_l = idx >> 4;
                 const float* sp = &out_s[co_l * 65 + py * PC + 4 * x4];
-                *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * CO_BLK + co_l) * Hp + py0 + py) * Wp + px0 + 4 * x4) =
-                    make_float4(sp[0], sp[1], sp[2], sp[3]);
+                const size_t o = (((size_t)b * Cout + cb * CO_BLK + co_l) * Hp + py0 + py) * Wp + px0 + 4 * x4;
+                *reinterpret_cast<float4*>(y + o) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                if constexpr (AM) *reinterpret_cast<uchar4*>(amax + o) = *reinterpret_cast<const uchar4*>(&am_s[co_l * 68 + py * PC + 4 * x4]);
             }
             continue;
         }
@@ -338,14 +352,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 // per wave, 18 MFMAs per M-tile) with the next patch prefetched in registers; ~20 KB of LDS and <= 128 registers
 // let four workgroups share a CU, so one's staging / epilogue hides behind the others' MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CIN>
+template <int CIN, bool AM = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    int H, int W, int Cout, int Hp, int Wp, int tiles_x) {
+    unsigned char* __restrict__ amax, int H, int W, int Cout, int Hp, int Wp, int tiles_x) {
     constexpr int RS = 48;                                   // pixels per patch row: rows r, r+1 half a bank row apart
     constexpr int PLANE = 10 * RS;                           // pixels per split plane
     __shared__ __attribute__((aligned(16))) uint2 img[3 * PLANE];
     __shared__ float out_s[32 * 65];
+    __shared__ unsigned char am_s[AM ? 32 * 68 : 4];         // pooling arg max of the tile (training forward)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
@@ -455,8 +470,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v = fmaxf(fmaxf(acc[m][4 * q], acc[m][4 * q + 1]), fmaxf(acc[m][4 * q + 2], acc[m][4 * q + 3])) + bv;
-                out_s[i * 65 + (wy * 2 + m) * 16 + wx * 8 + 2 * q + h] = fmaxf(v, 0.f);
+                const int pos = (wy * 2 + m) * 16 + wx * 8 + 2 * q + h;
+                if constexpr (AM) {                          // first maximum wins, as ATen's max_pool2d
+                    float best = acc[m][4 * q];
+                    int bi = 0;
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (acc[m][4 * q + e] > best) { best = acc[m][4 * q + e]; bi = e; }
+                    out_s[i * 65 + pos] = fmaxf(best + bv, 0.f);
+                    am_s[i * 68 + pos] = (unsigned char)bi;
+                } else {
+                    const float v = fmaxf(fmaxf(acc[m][4 * q], acc[m][4 * q + 1]), fmaxf(acc[m][4 * q + 2], acc[m][4 * q + 3])) + bv;
+                    out_s[i * 65 + pos] = fmaxf(v, 0.f);
+                }
             }
         __syncthreads();                                    // pooled tile complete (and every wave is past its A reads)
         const int py0 = y0 >> 1, px0 = tx * 16;
@@ -464,14 +490,18 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
             for (int idx = tid; idx < 32 * 16; idx += 256) {
                 const int x4 = idx & 3, py = (idx >> 2) & 3, c = idx >> 4;
                 const float* sp = &out_s[c * 65 + py * 16 + 4 * x4];
-                *reinterpret_cast<float4*>(y + (((size_t)b * Cout + cb * 32 + c) * Hp + py0 + py) * Wp + px0 + 4 * x4) =
-                    make_float4(sp[0], sp[1], sp[2], sp[3]);
+                const size_t o = (((size_t)b * Cout + cb * 32 + c) * Hp + py0 + py) * Wp + px0 + 4 * x4;
+                *reinterpret_cast<float4*>(y + o) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                if constexpr (AM) *reinterpret_cast<uchar4*>(amax + o) = *reinterpret_cast<const uchar4*>(&am_s[c * 68 + py * 16 + 4 * x4]);
             }
         } else {
             for (int idx = tid; idx < 32 * 64; idx += 256) {
                 const int px = idx & 15, py = (idx >> 4) & 3, c = idx >> 6;
-                if (cb * 32 + c < Cout && py0 + py < Hp && px0 + px < Wp)
-                    y[(((size_t)b * Cout + cb * 32 + c) * Hp + py0 + py) * Wp + px0 + px] = out_s[c * 65 + py * 16 + px];
+                if (cb * 32 + c < Cout && py0 + py < Hp && px0 + px < Wp) {
+                    const size_t o = (((size_t)b * Cout + cb * 32 + c) * Hp + py0 + py) * Wp + px0 + px;
+                    y[o] = out_s[c * 65 + py * 16 + px];
+                    if constexpr (AM) amax[o] = am_s[c * 68 + py * 16 + px];
+                }
             }
         }
     }
@@ -524,6 +554,9 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
         if (full)                                                                                                     \
             hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, true>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y,  \
                                amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+        else if (amax)                                                                                                \
+            hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, false, true>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
         else                                                                                                          \
             hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, false>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, \
                                amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
@@ -540,15 +573,23 @@ bool i2l_conv_smallk_applicable(int Cin, int Cout) {
     return Cin >= 1 && Cin <= 3 && Cout % 32 == 0;
 }
 
-int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
-                        hipStream_t s) {
+int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
+                        int H, int W, int Cout, hipStream_t s) {
     const int Hp = H / 2, Wp = W / 2;
     const int tiles_x = i2l_cdiv(2 * Wp, 32), bands = i2l_cdiv(2 * Hp, 8);
     if (bands > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
     dim3 grid(Cout / 32, bands, B);
-    if (Cin == 1) hipLaunchKernelGGL(conv3x3_smallk_bf16x3_kernel<1>, grid, dim3(256), 0, s, x, w, bias, y, H, W, Cout, Hp, Wp, tiles_x);
-    else if (Cin == 2) hipLaunchKernelGGL(conv3x3_smallk_bf16x3_kernel<2>, grid, dim3(256), 0, s, x, w, bias, y, H, W, Cout, Hp, Wp, tiles_x);
-    else hipLaunchKernelGGL(conv3x3_smallk_bf16x3_kernel<3>, grid, dim3(256), 0, s, x, w, bias, y, H, W, Cout, Hp, Wp, tiles_x);
+#define I2L_LAUNCH_SK(C, A) hipLaunchKernelGGL((conv3x3_smallk_bf16x3_kernel<C, A>), grid, dim3(256), 0, s, x, w, bias, y, amax, H, W, Cout, Hp, Wp, tiles_x)
+    if (amax) {
+        if (Cin == 1) I2L_LAUNCH_SK(1, true);
+        else if (Cin == 2) I2L_LAUNCH_SK(2, true);
+        else I2L_LAUNCH_SK(3, true);
+    } else {
+        if (Cin == 1) I2L_LAUNCH_SK(1, false);
+        else if (Cin == 2) I2L_LAUNCH_SK(2, false);
+        else I2L_LAUNCH_SK(3, false);
+    }
+#undef I2L_LAUNCH_SK
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }

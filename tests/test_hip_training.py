@@ -99,22 +99,47 @@ def test_ce_kernel_vs_torch():
         rel_close(dl.cpu().numpy(), ref_logits.grad.numpy(), 1e-5, "dlogits")
 
 
+@pytest.mark.parametrize("variant", ["default", "exact", "split_forward"])
 @pytest.mark.parametrize("name", SMALL + ["primary"])
-def test_encoder_backward_vs_oracle(name):
-    """d(sum(enc * r))/d(encoder params) against the oracle's autograd."""
+def test_encoder_backward_vs_oracle(name, variant):
+    """d(sum(enc * r))/d(encoder params) against the oracle's autograd, 3e-4 of each gradient's maximum (default kernels
+    and I2L_FLAG_EXACT_FP32).
+    The conv weight gradients are sums of ~10^5..10^6 products of both signs that cancel to ~1e-3 of their magnitude,
+    and they are non-smooth in the forward values (ReLU boundary, pooling arg max): two correct fp32 evaluations -- the
+    oracle in fp32 vs the oracle in fp64 -- already differ by up to 4e-3 of a gradient's maximum (recorded).  That is why
+    the training forward stays on the exact-fp32 kernels by default (they follow ATen's rounding, so the 3e-4 holds), and
+    why the opt-in I2L_FLAG_TRAIN_FWD_SPLIT forward (3 x bf16 split products, 0.11 ms per 64-image step faster) is
+    judged against the FLOAT64 oracle instead: 1e-2 of the maximum element-wise, 3e-4 on every gradient's norm."""
     d, cfg, m = build(name)
     sd = torch_state_dict(name)
     x = images(cfg)
     r = torch.from_numpy(synth.uniform(5, "probe", (4, cfg["embedding_dim"]), -1.0, 1.0))
-    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
-    enc_cpu = O.cnn_encoder({**sd, **params}, cfg, x)
-    (enc_cpu * r).sum().backward()
+
+    def oracle(dtype):
+        params = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+        enc_ = O.cnn_encoder({**{k: v.to(dtype) for k, v in sd.items()}, **params}, cfg, x.to(dtype))
+        (enc_ * r.to(dtype)).sum().backward()
+        return enc_.detach(), {k: p.grad for k, p in params.items()}
+    enc_cpu, g32 = oracle(torch.float32)
+    _, g64 = oracle(torch.float64)
     m.train()
+    m.encoder.kernel_flags = {"default": 0, "exact": _lib.FLAG_EXACT_FP32, "split_forward": _lib.FLAG_TRAIN_FWD_SPLIT}[variant]
     enc = m.encoder(x.to(DEV))
-    rel_close(enc.detach().cpu().numpy(), enc_cpu.detach().numpy(), 1e-5, "enc")
+    rel_close(enc.detach().cpu().numpy(), enc_cpu.numpy(), 1e-5, "enc")
     (enc * r.to(DEV)).sum().backward()
     for n, p in m.encoder.named_parameters():
-        rel_close(p.grad.cpu().numpy(), params["encoder." + n].grad.numpy(), 3e-4, n)
+        t = g64["encoder." + n]
+        scale = float(t.abs().max())
+        g = p.grad.cpu().double()
+        e_hip = float((g - t).abs().max()) / scale
+        e_ref = float((g32["encoder." + n].double() - t).abs().max()) / scale
+        record(f"{name} B=4 d{n} vs fp64 oracle [rel to max]: HIP {variant}", e_hip)
+        record(f"{name} B=4 d{n} vs fp64 oracle [rel to max]: fp32 oracle", e_ref)
+        if variant == "split_forward":
+            assert e_hip <= 1e-2, (n, e_hip, e_ref)
+            assert abs(float(g.norm()) - float(t.norm())) <= 3e-4 * float(t.norm()), n
+        else:
+            rel_close(p.grad.cpu().numpy(), g32["encoder." + n].numpy(), 3e-4, n)
 
 
 def test_conv_bwd_odd_shapes():
