@@ -117,8 +117,9 @@ def encoder_train_forward(encoder, x):
     return out, dict(x=x, blocks=blocks, amax=amax, out=out)
 
 
-def encoder_train_backward(enc, state, denc, grads):
-    """Fills ``grads`` (``encoder.named_parameters()`` names) from d(encoder_output)."""
+def encoder_train_backward(enc, state, denc, grads, after_linear=None):
+    """Fills ``grads`` (``encoder.named_parameters()`` names) from d(encoder_output).  ``after_linear`` is called once the
+    FC layer's backward has been enqueued (TrainStep starts the early part of the gradient all-reduce there)."""
     L = _lib.lib()
     denc = _lib.require_gpu(denc, "d encoder_output")
     dev = denc.device
@@ -134,6 +135,8 @@ def encoder_train_backward(enc, state, denc, grads):
                                          denc.data_ptr(), dfeat.data_ptr(), grads["embedding_layer.weight"].data_ptr(),
                                          grads["embedding_layer.bias"].data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
                                          enc.kernel_flags, _lib.stream_ptr()), "linear_bias_act_bwd")
+    if after_linear is not None:
+        after_linear()
     dy = dfeat
     for i in reversed(range(len(enc.conv_filters))):
         conv = enc.cnn_layers[3 * i]

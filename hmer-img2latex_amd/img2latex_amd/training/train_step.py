@@ -19,7 +19,7 @@ import torch
 from .. import _lib
 from ..model._train_fn import (decoder_train_backward, decoder_train_forward, encoder_train_backward,
                                encoder_train_forward)
-from .dp import all_reduce_gradients, broadcast_parameters, rank_of
+from .dp import OverlappedAllReduce, broadcast_parameters, rank_of
 
 
 class TrainStep:
@@ -37,13 +37,22 @@ class TrainStep:
         if not params or not params[0].is_cuda:
             raise RuntimeError("img2latex_amd: TrainStep needs the model on a ROCm device (no CPU fallback)")
         dev = params[0].device
-        # 16-byte aligned slices of one flat buffer; parameters become views into it (state_dict unchanged)
+        # 16-byte aligned slices of one flat buffer; parameters become views into it (state_dict unchanged).  The conv
+        # stack's parameters go LAST: their gradients are the last the backward pass produces, so everything in front
+        # of them can be all-reduced while the conv backward still runs (dp.OverlappedAllReduce)
         self.offsets: Dict[str, int] = {}
+        named = list(model.named_parameters())
+        late = [(n, p) for n, p in named if n.startswith("encoder.cnn_layers.")]
+        early = [(n, p) for n, p in named if not n.startswith("encoder.cnn_layers.")]
         off = 0
-        for name, p in model.named_parameters():
+        for name, p in early + late:
+            if late and name == late[0][0]:
+                self.n_early = off
             self.offsets[name] = off
             off += (p.numel() + 3) // 4 * 4
         self.n = off
+        if not late:
+            self.n_early = off
         self.flat_params = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.flat_grads = torch.zeros(self.n + 4, dtype=torch.float32, device=dev)   # [n] loss sum, [n+1] count
         self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=dev)
@@ -58,6 +67,7 @@ class TrainStep:
                 p.data = view
                 self.grad_views[name] = self.flat_grads[o:o + p.numel()].view_as(p)
         broadcast_parameters(self.flat_params, 0, self.group)
+        self._reducer = OverlappedAllReduce(self.flat_grads, self.n_early, self.group)
         L = _lib.lib()
         # zeroed once: besides scratch it carries the count of skipped (non-finite) updates across calls
         self._opt_ws = torch.zeros(L.i2l_optimizer_workspace_bytes(), dtype=torch.uint8, device=dev)
@@ -88,13 +98,14 @@ class TrainStep:
         dgr = {n[len("decoder."):]: g for n, g in self.grad_views.items() if n.startswith("decoder.")}
         denc = decoder_train_backward(model.decoder, dec_state, dlogits, dgr)
         egr = {n[len("encoder."):]: g for n, g in self.grad_views.items() if n.startswith("encoder.")}
-        encoder_train_backward(model.encoder, enc_state, denc, egr)
+        # decoder + FC gradients are final once the FC backward is enqueued: their all-reduce starts there
+        encoder_train_backward(model.encoder, enc_state, denc, egr, after_linear=self._reducer.start_early)
         return logits
 
     def apply(self) -> None:
         """All-reduce (data parallel), then clip + Adam; bumps the step counter."""
         L = _lib.lib()
-        all_reduce_gradients(self.flat_grads, self.group)
+        self._reducer.finish()
         self.step_count += 1
         _lib.check(L.i2l_grad_clip_adam_step(
             self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.exp_avg.data_ptr(),

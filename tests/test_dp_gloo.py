@@ -94,3 +94,33 @@ def test_two_rank_gloo_allreduce_equals_full_batch():
     assert abs(out["loss"][0] - out["loss"][1]) < 1e-6
     assert out["max_err"] <= 1e-6 * max(1.0, out["scale"]), dict(out)
     assert out["identical_across_ranks"]
+
+
+def _overlap_worker(rank, world, port, out):
+    from img2latex_amd.training.dp import OverlappedAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, split = 10007, 9000
+    base = torch.from_numpy(synth.uniform(50 + rank, "flat", (n,), -1.0, 1.0))
+    a, b, c = base.clone(), base.clone(), base.clone()
+    all_reduce_gradients(a)                                  # the single all-reduce
+    r = OverlappedAllReduce(b, split)
+    r.start_early()                                          # early piece in flight ...
+    b[split:] += 0.0                                         # ... while "conv backward" still writes the late piece
+    r.finish()
+    r2 = OverlappedAllReduce(c, split)                       # finish() alone = one all-reduce of everything
+    r2.finish()
+    if rank == 0:
+        out["two_piece_equals_single"] = bool(torch.equal(a, b))
+        out["finish_only_equals_single"] = bool(torch.equal(a, c))
+    dist.destroy_process_group()
+
+
+def test_two_piece_allreduce_is_bit_identical_to_one():
+    """dp.OverlappedAllReduce: [decoder + FC gradients] started early, [conv gradients, loss sum, count] at the end:
+    element-wise the same sums as ONE all-reduce of the flat buffer (world size 2, gloo)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out["two_piece_equals_single"] and out["finish_only_equals_single"]
