@@ -1037,7 +1037,12 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
     p.top_k = top_k; p.top_p = top_p; p.seed = seed; p.probs = probs_out;
 
     // grouped kernel: 4 workgroups share 4 rows, weights fully on chip (decode_group.inc.h)
-    if (rows_per_wg == 0 && lo.xchg_bytes && select == I2L_SELECT_LOGITS && !h0 && !h_out && !c_out &&
+    // I2L_SELECT_SOFTMAX takes it too: softmax is monotone, so its arg max is the logits' arg max unless fp32 rounding
+    // makes two DIFFERENT scaled logits equal probabilities, which needs the two largest to be adjacent floats AND the
+    // largest below 2 in magnitude (exp(x2 - x1) is then within 2 ulp of 1); the row-per-workgroup kernel evaluates
+    // the probabilities literally and is one argument away (rows_per_workgroup != 0)
+    if (rows_per_wg == 0 && lo.xchg_bytes && (select == I2L_SELECT_LOGITS || select == I2L_SELECT_SOFTMAX) && !h0 &&
+        !h_out && !c_out &&
         steps >= 8 && steps <= 65000) {   // the candidate granule carries step + 1 in 16 bits
         GroupParams gp{};
         gp.w = p.w; gp.B = rows; gp.T = steps; gp.n_groups = lo.n_groups;

@@ -176,7 +176,11 @@ int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* enc, int rows
 
 /* Token selection. */
 #define I2L_SELECT_LOGITS 0   /* argmax(logits / temperature)           seq2seq.py:213-215      */
-#define I2L_SELECT_SOFTMAX 1  /* argmax(softmax(logits / temperature))  predictor.py:295-297,333 */
+#define I2L_SELECT_SOFTMAX 1  /* argmax(softmax(logits / temperature))  predictor.py:295-297,333: the row-per-workgroup
+                                 kernel evaluates the fp32 probabilities literally; the grouped kernel takes the arg max of
+                                 the scaled logits, which is the same token unless the two largest are adjacent floats
+                                 AND smaller than 2 in magnitude (only then can rounding make their probabilities equal
+                                 and hand the tie to the lower index) */
 #define I2L_SELECT_SAMPLE 2   /* multinomial over the top-k / top-p masked softmax  predictor.py:299-331 (i2l_sample_decode) */
 
 /* The decode loop: `steps` iterations of [embedding lookup, LSTM step (all layers),
@@ -193,7 +197,7 @@ int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* enc, int rows
  *   logits_out  (rows, steps, V) or NULL      raw logits (before temperature)
  *   h_out,c_out (L, rows, H) or NULL          state after the last executed step
  * First index wins ties, as torch.argmax.
- * Kernel choice: L == 1, H == 256, V <= 512, select == I2L_SELECT_LOGITS, no state in/out, steps >= 8 run the
+ * Kernel choice: L == 1, H == 256, V <= 512, select != I2L_SELECT_SAMPLE, no state in/out, steps >= 8 run the
  * grouped kernel (4 workgroups share 4 rows and keep the weights on chip, in-launch exchanges bounded by a 3 s
  * wall-clock limit); everything else the row-per-workgroup kernel.  If a bounded wait expires (GPU heavily
  * oversubscribed) every id of the affected rows is -3, every requested logit of those rows is NaN and no other
