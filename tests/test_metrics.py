@@ -112,3 +112,22 @@ def test_device_id_matrices_and_long_sequences():
         p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
         assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), i
         assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), i
+
+
+@pytest.mark.gpu
+def test_very_long_sequences():
+    """max_len 1400 (five passes of the workgroup per anti-diagonal, 28 KB of LDS): same integers as the oracle (lengths
+    straddling the workgroup size, repeated tokens, one empty side)."""
+    from img2latex_amd.training import metrics as M
+    dev = torch.device("cuda:0")
+    B, W = 4, 1400
+    P = synth.randint(41, "p", (B, W), 1, 5).astype(np.int32)
+    T = synth.randint(42, "t", (B, W), 1, 5).astype(np.int32)
+    pl = np.array([1400, 63, 0, 1301], np.int32)
+    tl = np.array([1399, 1400, 7, 65], np.int32)
+    st = M.device_sequence_statistics(torch.from_numpy(P).to(dev), torch.from_numpy(pl).to(dev),
+                                      torch.from_numpy(T).to(dev), torch.from_numpy(tl).to(dev), 4, PAD)
+    for i in range(B):
+        p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
+        assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), i
+        assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), i
