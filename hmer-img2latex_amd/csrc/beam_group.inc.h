@@ -63,6 +63,7 @@ struct BeamGroupParams {
     double* score_out;
     u64_t* xchg;          // [n_groups][2][4][BG_GRAN]
     unsigned* status;
+    int agent_scope;      // != 0: every exchange store at agent scope (I2L_FLAG_AGENT_SCOPE_EXCHANGE)
 };
 
 // all-reduce over the 64 lanes of a wave: 4 rotate steps inside each row of 16, then the 4 row results
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
         if (lane == 0) { flg[1] = (all_same && !bad) ? 1 : 0; if (bad) flg[0] = 1; }
     }
     __syncthreads();
-    const bool local = flg[1] != 0;
+    const bool local = flg[1] != 0 && !p.agent_scope;
 
     float c_new[BG_NP];
 #pragma unroll

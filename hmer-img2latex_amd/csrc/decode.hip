@@ -979,19 +979,19 @@ namespace {
 int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
                   const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
                   int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
-                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg = 0);
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg = 0, int flags = 0);
 }
 
 extern "C" int i2l_greedy_decode_ex(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
                                     const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
                                     float temperature, int select, int stop, int end_id, int rows_per_workgroup,
-                                    int32_t* ids_out, float* logits_out, float* h_out, float* c_out,
+                                    int32_t* ids_out, float* logits_out, float* h_out, float* c_out, int flags,
                                     i2l_stream_t stream) {
     if (select != I2L_SELECT_LOGITS && select != I2L_SELECT_SOFTMAX) return I2L_ERR_ARG;
     if (rows_per_workgroup != 0 && rows_per_workgroup != 1 && rows_per_workgroup != 2 && rows_per_workgroup != 4)
         return I2L_ERR_ARG;
     return launch_decode(w, workspace, rows, steps, tok0, forced, h0, c0, temperature, select, stop, end_id, 0, 0.f, 0ull,
-                         ids_out, logits_out, nullptr, h_out, c_out, stream, rows_per_workgroup);
+                         ids_out, logits_out, nullptr, h_out, c_out, stream, rows_per_workgroup, flags);
 }
 
 extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
@@ -1017,7 +1017,7 @@ namespace {
 int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
                   const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
                   int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
-                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg) {
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg, int flags) {
     int rc = check_weights(w);
     if (rc != I2L_OK) return rc;
     if (!workspace || !tok0 || rows <= 0 || steps <= 0) return I2L_ERR_ARG;
@@ -1051,6 +1051,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
         char* xb = const_cast<char*>(base) + lo.xchg;           // scratch region of the workspace
         gp.status = reinterpret_cast<unsigned*>(xb);
         gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
+        gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
         hipStream_t gs = i2l_s(stream);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP_LDS) == hipSuccess) {
@@ -1177,6 +1178,7 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
         const size_t xbytes = GROUP_STATUS_BYTES + (size_t)i2l_cdiv(gp.n_groups, 8) * 8 * BEAM_XCHG_PER_GROUP;
         gp.status = reinterpret_cast<unsigned*>(xb);
         gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
+        gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
         if (hipMemsetAsync(xb, 0, xbytes, s) != hipSuccess) return I2L_ERR_LAUNCH;
         switch (beam) {
             case 2: return launch_beam_group<2>(gp, s);

@@ -30,10 +30,18 @@
 // after reading that slot.  The granule block is zeroed by a memset node before every launch.
 //
 // Progress: the members of a group are workgroups 32a + x + 8k (k = 0..3) -- one XCD under round-robin placement
-// (speed only) -- and workgroups are dispatched in index order, so whenever a member is resident every lower
-// index has been dispatched and some complete group can always run to its end and free its CUs.  Every poll is
-// bounded by a wall-clock limit: on expiry the workgroup raises status[0], fills its ids with -3 and exits, its
-// peers follow by their own limits, and the host wrapper reports the failure; the GPU is never left spinning.
+// (speed only) -- and workgroups are dispatched in index order, so on a GPU with at least the 32 CUs of one grid
+// slice free some complete group is resident and runs to its end, freeing its CUs for the next.  That is an
+// assumption about the dispatcher and about what else runs on the device, not something HIP promises (the launch
+// is not cooperative): with fewer CUs free every resident workgroup may be waiting for a member that is not, so
+// EVERY poll is bounded by a wall-clock limit: on expiry the workgroup raises status[0], fills its ids with -3 (and
+// its logits with NaN) and exits, its peers follow by their own limits, and the host wrapper reports the failure
+// and re-runs on the row-per-workgroup kernel; the GPU is never left spinning.
+// Memory model: the granule stores are relaxed atomics at AGENT scope (sc1, write-through) and the polls agent-scope
+// loads -- conformant HSA.  When the four members measure themselves on one XCD the stores drop to WORKGROUP scope
+// (a plain store that gfx950's write-through L1 forwards to the XCD's L2, where the peers' L1-bypassing polls find
+// it: 1.28 -> 0.50 us per exchange); that relies on the gfx950 cache hierarchy, not on the memory model, so the
+// conformant flavour stays selectable (I2L_FLAG_AGENT_SCOPE_EXCHANGE) and tested.
 #include "group_common.inc.h"
 
 constexpr int GQ = 4;                    // workgroups (= rows) per group
@@ -57,6 +65,7 @@ struct GroupParams {
     int use_temp, stop, end_id;
     u64_t* xchg;          // [n_groups][2][GQ][GRAN]
     unsigned* status;     // [0] != 0: a poll timed out
+    int agent_scope;      // != 0: every exchange store at agent scope (I2L_FLAG_AGENT_SCOPE_EXCHANGE)
 };
 
 constexpr int DPP_SHL12 = 0x10C;
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
         if (lane == 0) { cnt_s[3] = (all_same && !bad) ? 1 : 0; if (bad) cnt_s[2] = 1; }
     }
     __syncthreads();
-    const bool local = cnt_s[3] != 0;
+    const bool local = cnt_s[3] != 0 && !p.agent_scope;
 
     // token of the row this lane's cell belongs to (row ke & 3) and its table row, gathered as early as the token is known
     const int my_r = ke & 3;

@@ -20,6 +20,7 @@ struct TrainGroupFwd {
     float* ACT; float* C; float* Hout; float* Hprev;
     u64_t* xchg;          // [n_groups][2][4][TGF_GRAN]
     unsigned* status;
+    int agent_scope;      // != 0: every exchange store at agent scope (I2L_FLAG_AGENT_SCOPE_EXCHANGE)
 };
 struct TrainGroupBwd {
     int B, T, n_groups;
@@ -28,6 +29,7 @@ struct TrainGroupBwd {
     float* DG;            // [B*T][4H] standard gate order
     u64_t* xchg;          // [n_groups][2][4][TGB_GRAN]
     unsigned* status;
+    int agent_scope;      // != 0: every exchange store at agent scope (I2L_FLAG_AGENT_SCOPE_EXCHANGE)
 };
 
 // Are the four members on one XCD?  (decode_group.inc.h: measured, never assumed.)  Returns via LDS word flag[1];
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group_kernel(TrainGroupFwd
     }
     for (int idx = tid; idx < 2 * 1024; idx += TGT) (&h_s[0][0])[idx] = 0.f;
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGF_GRAN;
-    const bool local = group_placement_local(xg, TGF_GRAN, 272, m, flag);      // barrier inside: h_s zeroed
+    const bool local = group_placement_local(xg, TGF_GRAN, 272, m, flag) && !p.agent_scope;      // barrier inside: h_s zeroed
     const int row = min(row0 + kr, B - 1);
     const bool live = ke < 4 && row0 + kr < B;                                  // this lane owns (unit, row kr)
     float c_own = 0.f, h_own = 0.f;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group_kernel(TrainGroupBwd
     const int row = min(row0 + o_row, B - 1);
     const bool owner = ns < 16, live = owner && row0 + o_row < B;
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGB_GRAN;
-    const bool local = group_placement_local(xg, TGB_GRAN, 1024, m, flag);
+    const bool local = group_placement_local(xg, TGB_GRAN, 1024, m, flag) && !p.agent_scope;
     float dh_rec = 0.f, dc_next = 0.f;
     bool failed = false;
     for (int t = T - 1; t >= 0; --t) {

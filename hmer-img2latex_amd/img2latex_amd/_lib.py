@@ -22,6 +22,7 @@ PREP_WEIGHTS, PREP_ROWS, PREP_ALL = 1, 2, 3
 MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
 # kernel-selection flags (include/img2latex_hip.h I2L_FLAG_*): explicit arguments, the library reads no environment
 FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM, FLAG_TRAIN_FWD_SPLIT = 0x1, 0x2, 0x4, 0x8, 0x10
+FLAG_AGENT_SCOPE_EXCHANGE = 0x20
 
 
 def flag_resnet_ring_depth(n: int) -> int:
@@ -72,7 +73,7 @@ _SIGNATURES = {
                                   c_void_p]),
     "i2l_greedy_decode_ex": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p]),
+                                     c_void_p, c_int, c_void_p]),
     "i2l_sample_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                   c_int, c_float, c_uint64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),

@@ -80,7 +80,7 @@ class LSTMDecoder(nn.Module):
         self._ws: Optional[torch.Tensor] = None      # workspace of the CURRENT stream (see _select_workspace)
         self._ws_key = None          # (rows, weight versions) the weight images in _ws were built for
         self._ws_by_stream = {}      # stream handle -> (workspace, key): concurrent decodes must not share one
-        self.kernel_flags = 0        # training kernels: _lib.FLAG_NO_GROUP / _lib.FLAG_EXACT_FP32
+        self.kernel_flags = 0        # _lib.FLAG_NO_GROUP / FLAG_EXACT_FP32 (training), FLAG_AGENT_SCOPE_EXCHANGE (all grouped)
 
     # ------------------------------------------------------------------ plumbing
     def _weights_struct(self):
@@ -141,7 +141,8 @@ class LSTMDecoder(nn.Module):
                   forced: Optional[torch.Tensor] = None, hidden: Optional[Hidden] = None,
                   temperature: float = 1.0, select: int = _lib.SELECT_LOGITS, stop: int = _lib.STOP_NONE,
                   end_id: int = -1, want_ids: bool = True, want_logits: bool = False,
-                  want_state: bool = False, reuse_weight_images: bool = True, rows_per_workgroup: int = 0):
+                  want_state: bool = False, reuse_weight_images: bool = True, rows_per_workgroup: int = 0,
+                  flags: int = 0):
         """prepare + one persistent i2l_greedy_decode launch.  Returns (ids, logits, (h, c))."""
         w, keep, enc = self.prepare(encoder_output, reuse_weight_images)
         rows, dev = enc.shape[0], enc.device
@@ -166,7 +167,8 @@ class LSTMDecoder(nn.Module):
         _lib.check(_lib.lib().i2l_greedy_decode_ex(
             ctypes.byref(w), self._ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(forced), _lib.ptr(h0),
             _lib.ptr(c0), float(temperature), select, stop, int(end_id), int(rows_per_workgroup), _lib.ptr(ids),
-            _lib.ptr(logits), _lib.ptr(h), _lib.ptr(c), _lib.stream_ptr()), "greedy_decode")
+            _lib.ptr(logits), _lib.ptr(h), _lib.ptr(c), int(flags) | int(self.kernel_flags), _lib.stream_ptr()),
+            "greedy_decode")
         _lib.mark("decode")
         del keep
         return ids, logits, ((h, c) if want_state else None)

@@ -155,13 +155,13 @@ class Seq2SeqModel(nn.Module):
                                          int(start_token_id), int(end_token_id), bws.data_ptr(), nbytes,
                                          seq.data_ptr(), ln.data_ptr(), score.data_ptr(), int(fl), _lib.stream_ptr()),
                        "beam_decode")
-        launch(flags)
+        launch(flags | int(dec.kernel_flags))
         seq_h, ln_h = seq.cpu(), ln.cpu()
         if min(ln_h.tolist()) <= -3:
             # the grouped kernel needs its four workgroups resident together; on a GPU shared with other work a
             # poll can time out (len -3): run the one-workgroup-per-image kernel instead
             warnings.warn("img2latex_amd: grouped beam search timed out, re-running with one workgroup per image")
-            launch(flags | _lib.FLAG_NO_GROUP)
+            launch(flags | int(dec.kernel_flags) | _lib.FLAG_NO_GROUP)
             seq_h, ln_h = seq.cpu(), ln.cpu()
         del keep
         lens = ln_h.tolist()                                   # one conversion each, then plain list slices

@@ -53,6 +53,10 @@ typedef void* i2l_stream_t;
 #define I2L_FLAG_TRAIN_FWD_SPLIT 0x10  /* i2l_conv3x3_relu_pool2_fwd with argmax_out (training forward): 3 x bf16 split
                                           kernels instead of the exact-fp32 ones (faster; conv gradients then keep the
                                           float64 class of error but no longer follow ATen's rounding, see conv.hip)   */
+#define I2L_FLAG_AGENT_SCOPE_EXCHANGE 0x20 /* grouped kernels (greedy, beam, training recurrences): every exchange store at
+                                          agent scope (sc1, write-through) -- the HSA-memory-model-conformant flavour --
+                                          even when the group's members share an XCD and the faster L2-local
+                                          (workgroup-scope) stores would be used; same results, ~0.8 us per step slower */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
 
 int i2l_version(void);
@@ -210,13 +214,14 @@ int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int r
                       i2l_stream_t stream);
 
 /* Same as i2l_greedy_decode with an explicit number of batch rows per workgroup (0 = automatic, else 1, 2
- * or 4; a non-zero value also selects the row-per-workgroup kernel).  Rows per workgroup > 1 leaves compute units free for another stream (the weight stream of a
+ * or 4; a non-zero value also selects the row-per-workgroup kernel) and flags (I2L_FLAG_AGENT_SCOPE_EXCHANGE).  Rows per workgroup > 1 leaves compute units free for another stream (the weight stream of a
  * workgroup is shared by its rows): GreedyPipeline runs the decode of batch i on half of the chip while the
  * encoder of batch i+1 runs on the other half.  Results do not depend on this parameter. */
 int i2l_greedy_decode_ex(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
                          const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
                          float temperature, int select, int stop, int end_id, int rows_per_workgroup,
-                         int32_t* ids_out, float* logits_out, float* h_out, float* c_out, i2l_stream_t stream);
+                         int32_t* ids_out, float* logits_out, float* h_out, float* c_out, int flags,
+                         i2l_stream_t stream);
 
 /* The sampling branch of Predictor.predict_batch (predictor.py:295-331, taken when temperature > 0 and
  * (top_k > 0 or top_p > 0)): probs = softmax(logits/T); top-k keeps p >= k-th largest; top-p drops a

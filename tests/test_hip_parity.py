@@ -796,3 +796,41 @@ def test_softmax_selection_grouped_vs_literal():
             same_rows = (a == b).all(axis=1).mean()
             assert same_rows >= 0.97, (temp, same_rows)
             assert (a == -1).sum() > 0                       # some rows did stop early
+
+
+def test_agent_scope_exchange_gives_identical_results():
+    """The grouped kernels publish their exchange granules with workgroup-scope (L2-local) stores when the members of
+    a group measure themselves on one XCD -- fast, but resting on gfx950's cache hierarchy rather than on the HSA memory
+    model.  I2L_FLAG_AGENT_SCOPE_EXCHANGE keeps every store at agent scope (the conformant flavour): greedy ids, beam
+    sequences / scores must be bit-identical to the default, one training step equal to rounding."""
+    from img2latex_amd.training import TrainStep
+    d, cfg, sd_kw = load("primary_cfg2_clock")
+    m, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(DEV)
+    with torch.no_grad():
+        enc = m.encoder(x)
+        fast, _ = m.greedy_ids(enc, START, END, 150)
+        fast_b, fast_s = m.beam_search_batch(enc[:37].contiguous(), START, END, 48, 5, return_scores=True)
+        m.decoder.kernel_flags = _lib.FLAG_AGENT_SCOPE_EXCHANGE
+        try:
+            slow, _ = m.greedy_ids(enc, START, END, 150)
+            slow_b, slow_s = m.beam_search_batch(enc[:37].contiguous(), START, END, 48, 5, return_scores=True)
+        finally:
+            m.decoder.kernel_flags = 0
+    assert torch.equal(_lib.check_ids(slow.cpu()), _lib.check_ids(fast.cpu()))
+    assert slow_b == fast_b and slow_s == fast_s
+    cfg3 = synth.model_config(dropout=0.0)
+    np_sd = synth.make_state_dict(cfg3, seed=42)
+    xs = torch.from_numpy(synth.make_images(8, cfg3, seed=5)).to(DEV)
+    forms = torch.from_numpy(synth.make_formulas(8, 40, cfg3["vocab_size"], seed=6)).to(DEV)
+    outs = []
+    for flags in (0, _lib.FLAG_AGENT_SCOPE_EXCHANGE):
+        mm = Seq2SeqModel("cnn_lstm", cfg3["vocab_size"], synth.encoder_params(cfg3), synth.decoder_params(cfg3))
+        mm.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in np_sd.items()})
+        mm = mm.to(DEV)
+        mm.decoder.kernel_flags = flags
+        ts = TrainStep(mm)
+        ts.step(xs, forms)
+        outs.append(ts.flat_params.clone())
+    # (the embedding-gradient scatter adds with atomics, so two runs of the SAME kernels agree to rounding, not to the bit)
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-6
