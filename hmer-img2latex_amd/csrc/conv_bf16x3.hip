@@ -108,7 +108,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave / WX, wx = wave % WX;
-    const int cb = blockIdx.x;
+    // XCD-aware ids: workgroups are placed round-robin over the 8 XCDs (id mod 8), each with its own L2.  The
+    // 64-channel blocks of ONE tile walk read the same input patches, so they get ids 8 apart (same XCD, dispatched
+    // together, same pace): the second block's reads hit that XCD's L2 instead of going to HBM again.
+    const int co_blocks_g = (Cout + CO_BLK - 1) / CO_BLK;
+    const int lin = blockIdx.x, within = lin % (8 * co_blocks_g);
+    const int cb = within >> 3;
+    const int walk = (lin / (8 * co_blocks_g)) * 8 + (within & 7);
     const int i = lane & 31, h = lane >> 5;
     const int dx = i & 1, dy = (i >> 1) & 1, pp = i >> 2;
     // operand bases in 16-byte pieces
@@ -194,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     // during the last phases of the current one, so only the first tile pays a prologue.
     // Per chunk: 3 phases (filter rows) of 3 taps x 24 MFMAs per wave.
     const int n_phases = 3 * n_chunks;
-    const int it0 = blockIdx.y * items_per_wg, it_end = min(it0 + items_per_wg, n_items);
+    const int it0 = walk * items_per_wg, it_end = min(it0 + items_per_wg, n_items);
+    if (it0 >= n_items) return;
     setup_fetch(it0);
     fetch_x(0);
     fetch_w(0);
@@ -547,8 +554,8 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     const int n_items = (int)n_items_ll;
     int items_per_wg = (int)((n_items_ll * co_blocks + 511) / 512);
     if (items_per_wg < 1) items_per_wg = 1;
-    while (i2l_cdiv(n_items, items_per_wg) > 65535) ++items_per_wg;
-    dim3 grid(co_blocks, i2l_cdiv(n_items, items_per_wg));
+    const int walks = i2l_cdiv(n_items, items_per_wg);
+    dim3 grid((unsigned)(i2l_cdiv(walks, 8) * 8 * co_blocks));       // ids decoded in the kernel (XCD-aware)
 #define I2L_LAUNCH3(WXV)                                                                                              \
     do {                                                                                                              \
         if (full)                                                                                                     \
