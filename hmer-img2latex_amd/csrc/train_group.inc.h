@@ -314,3 +314,255 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group_kernel(TrainGroupBwd
     }
     (void)lane;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two rows per group (B <= 128: BASELINE configs[3] runs 64 rows per GPU).  With four rows per group 64 rows keep only
+// 64 of the 256 CUs busy and a step is bound by the in-group exchange plus the 4-row product (0.85 us of packed
+// FMAs); with two rows per group the same batch spreads over 128 CUs, the product halves and so does every
+// exchange (forward 64 x 2 h values, backward 256 x 2 gate gradients per member).  Same scheme, same granule
+// protocol, same numerics (the per-row arithmetic is identical, so results are bit-identical to the 4-row kernels).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TGF2_GRAN = 128 + 32;            // forward: h granules [unit 64][row 2] + placement line (at 144)
+constexpr int TGB2_GRAN = 512 + 16;            // backward: gate-gradient granules [gate 4][unit 64][row 2] + placement (at 512)
+constexpr int DPP_SHL2 = 0x102, DPP_SHL6 = 0x106;
+
+// acc[4 values] (one row pair each) += w4 (4 gates or units) x h2 (2 rows)
+__device__ __forceinline__ void fma_4x2(f32x2 (&acc)[4], f32x2 w01, f32x2 w23, f32x2 h) {
+    pkfma_lo(acc[0], w01, h); pkfma_hi(acc[1], w01, h);
+    pkfma_lo(acc[2], w23, h); pkfma_hi(acc[3], w23, h);
+}
+
+__global__ __launch_bounds__(TGT) void lstm_train_fwd_group2_kernel(TrainGroupFwd p) {
+    __shared__ __attribute__((aligned(16))) float h_s[2][512];     // [parity][k][row]: h of the previous step
+    __shared__ int flag[4];
+    const int tid = threadIdx.x;
+    const int within = blockIdx.x & 31;
+    const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
+    if (group >= p.n_groups) return;
+    const int B = p.B, T = p.T;
+    const int row0 = group * 2;
+    const int ul = tid >> 3, ke = tid & 7, kr = ke & 1;
+    const int unit = 64 * m + ul;
+    constexpr int G = 1024, H = 256;
+    f32x2 wreg[32][2];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p.WhhT + (size_t)(8 * j + ke) * G + 4 * unit);
+        wreg[j][0] = f32x2{t4.x, t4.y};
+        wreg[j][1] = f32x2{t4.z, t4.w};
+    }
+    for (int idx = tid; idx < 2 * 512; idx += TGT) (&h_s[0][0])[idx] = 0.f;
+    u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGF2_GRAN;
+    const bool local = group_placement_local(xg, TGF2_GRAN, 144, m, flag) && !p.agent_scope;   // barrier inside: h_s zeroed
+    const int row = min(row0 + kr, B - 1);
+    const bool live = ke < 2 && row0 + kr < B;                                  // this lane owns (unit, row kr)
+    float c_own = 0.f, h_own = 0.f;
+    bool failed = false;
+    int t = 0;
+    for (; t < T; ++t) {
+        const size_t bt = (size_t)row * T + t;
+        const float4 gx = *reinterpret_cast<const float4*>(p.GX + bt * G + 4 * unit);
+        f32x2 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = splat2(0.f);
+        if (t > 0) {
+            const f32x2* hq2 = reinterpret_cast<const f32x2*>(h_s[t & 1]) + ke;
+            f32x2 hb[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hb[0][i] = hq2[8 * i];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b + 1 < 8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hb[(b + 1) & 1][i] = hq2[8 * ((b + 1) * 4 + i)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fma_4x2(acc, wreg[b * 4 + i][0], wreg[b * 4 + i][1], hb[b & 1][i]);
+            }
+        }
+        {
+            // fold the 8 k-slices: 8 -> 4 -> 2 -> 1 value per lane: lane ke holds gate 2*(ke>>2) + (ke>>1 & 1) of row ke & 1
+            const bool b0 = ke & 1, b1 = ke & 2, b2 = ke & 4;
+            float wv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ux = rs_level<DPP_HMIRROR>(acc[e].x, acc[2 + e].x, b2);
+                const float uy = rs_level<DPP_HMIRROR>(acc[e].y, acc[2 + e].y, b2);
+                wv[e] = rs_level<DPP_XOR1>(ux, uy, b0);
+            }
+            const float zi = rs_level<DPP_XOR2>(wv[0], wv[1], b1);
+            const float zf = dpp_f<DPP_SHL2>(zi), zg = dpp_f<DPP_SHL4>(zi), zo = dpp_f<DPP_SHL6>(zi);
+            const float ig = sigmoidf_(gx.x + zi), fg = sigmoidf_(gx.y + zf);
+            const float gg = tanhf(gx.z + zg), og = sigmoidf_(gx.w + zo);
+            const float h_prev = h_own;
+            c_own = fg * c_own + ig * gg;
+            h_own = og * tanhf(c_own);
+            if (live) {
+                *reinterpret_cast<float4*>(p.ACT + bt * G + 4 * unit) = make_float4(ig, fg, gg, og);
+                p.C[bt * H + unit] = c_own;
+                p.Hout[bt * H + unit] = h_own;
+                p.Hprev[bt * H + unit] = h_prev;
+            }
+        }
+        if (t + 1 == T) break;
+        const unsigned epoch = (unsigned)t + 1u;
+        u64_t* slot = xg + (size_t)(t & 1) * 4 * TGF2_GRAN;
+        if (ke < 2) store_granule(slot + (size_t)m * TGF2_GRAN + ul * 2 + ke, granule(epoch, h_own), local);
+        {
+            const int gi = tid & 127, pi = min(tid >> 7, 2);
+            const int q = pi + (pi >= m ? 1 : 0);
+            const u64_t* pa_ = slot + (size_t)q * TGF2_GRAN + gi;
+            u64_t g0 = 0;
+            long long t_start = 0;
+            unsigned spins = 0;
+            if (tid < 384) {
+                for (;;) {
+                    g0 = load_granule(pa_);
+                    if ((unsigned)(g0 >> 32) == epoch) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0) {
+                        const long long now = (long long)wall_clock64();
+                        if (t_start == 0) t_start = now;
+                        else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
+                    }
+                }
+            }
+            float* hn = h_s[(t + 1) & 1];
+            if (tid < 384) hn[q * 128 + gi] = __uint_as_float((unsigned)g0);
+            if (ke < 2) hn[m * 128 + ul * 2 + ke] = h_own;
+        }
+        if (failed) flag[0] = 1;
+        __syncthreads();
+        if (flag[0]) { failed = true; break; }
+    }
+    if (failed || flag[0]) {
+        if (tid == 0) atomicOr(p.status, 1u);
+        if (live) for (int tt = 0; tt < T; ++tt) p.Hout[((size_t)row * T + tt) * H + unit] = __int_as_float(0x7fc00000);
+    }
+}
+
+__global__ __launch_bounds__(TGT) void lstm_train_bwd_group2_kernel(TrainGroupBwd p) {
+    __shared__ __attribute__((aligned(16))) float dgs[2][2048];    // [parity][gate row n][row]: gate gradients of a step
+    __shared__ int flag[4];
+    const int tid = threadIdx.x;
+    const int within = blockIdx.x & 31;
+    const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
+    if (group >= p.n_groups) return;
+    const int B = p.B, T = p.T;
+    const int row0 = group * 2;
+    constexpr int G = 1024, H = 256;
+    // product: thread = (unit quad jq, n slice ns): dh[4 units][2 rows] += Whh[32 i + ns][units] dG[32 i + ns][rows]
+    const int jq = tid >> 5, ns = tid & 31;
+    f32x2 wreg[32][2];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p.Whh + (size_t)(32 * i + ns) * H + 64 * m + 4 * jq);
+        wreg[i][0] = f32x2{t4.x, t4.y};
+        wreg[i][1] = f32x2{t4.z, t4.w};
+    }
+    // after the fold the lane owns dh of (unit 4 jq + o_col, row o_row); lanes ns < 8 run the cell backward for it
+    const int o_row = ns & 1, o_col = ((ns >> 2) & 1) * 2 + ((ns >> 1) & 1);
+    const int ul = 4 * jq + o_col, unit = 64 * m + ul;
+    const int row = min(row0 + o_row, B - 1);
+    const bool owner = ns < 8, live = owner && row0 + o_row < B;
+    u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGB2_GRAN;
+    const bool local = group_placement_local(xg, TGB2_GRAN, 512, m, flag) && !p.agent_scope;
+    float dh_rec = 0.f, dc_next = 0.f;
+    bool failed = false;
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        const unsigned epoch = (unsigned)(T - t);
+        const size_t bt = (size_t)row * T + t;
+        u64_t* slot = xg + (size_t)par * 4 * TGB2_GRAN;
+        float* dcur = dgs[par];
+        if (owner) {
+            const float4 a = *reinterpret_cast<const float4*>(p.ACT + bt * G + 4 * unit);
+            const float c = p.C[bt * H + unit];
+            const float cp = t > 0 ? p.C[(bt - 1) * H + unit] : 0.f;
+            const float dh = dh_rec + p.dHtop[bt * H + unit];
+            const float tc = tanhf(c);
+            const float d_o = dh * tc * a.w * (1.f - a.w);
+            const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
+            const float d_i = dc * a.z * a.x * (1.f - a.x);
+            const float d_f = dc * cp * a.y * (1.f - a.y);
+            const float d_g = dc * a.x * (1.f - a.z * a.z);
+            dc_next = dc * a.y;
+            const float dgv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (live) p.DG[bt * G + g * H + unit] = dgv[g];
+                dcur[(g * 256 + 64 * m + ul) * 2 + o_row] = dgv[g];
+                if (t > 0) store_granule(slot + (size_t)m * TGB2_GRAN + (g * 64 + ul) * 2 + o_row, granule(epoch, dgv[g]), local);
+            }
+        }
+        if (t == 0) break;
+        {
+            u64_t gr[3];
+            long long t_start = 0;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int qi = 0; qi < 3; ++qi) {
+                    const int q = qi + (qi >= m ? 1 : 0);
+                    gr[qi] = load_granule(slot + (size_t)q * TGB2_GRAN + tid);
+                    ok = ok && (unsigned)(gr[qi] >> 32) == epoch;
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255u) == 0) {
+                    const long long now = (long long)wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                const int q = qi + (qi >= m ? 1 : 0);
+                // granule tid = (g*64 + ul')*2 + row of member q  ->  gate row n = g*256 + 64 q + ul'
+                dcur[(tid >> 7) * 512 + 128 * q + (tid & 127)] = __uint_as_float((unsigned)gr[qi]);
+            }
+        }
+        if (failed) flag[0] = 1;
+        __syncthreads();
+        if (flag[0]) { failed = true; break; }
+        // dh_{t-1}[own units] = sum_n Whh[n][unit] dG[n]
+        f32x2 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = splat2(0.f);
+        {
+            const f32x2* dq2 = reinterpret_cast<const f32x2*>(dcur) + ns;
+            f32x2 hb[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hb[0][i] = dq2[32 * i];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b + 1 < 8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hb[(b + 1) & 1][i] = dq2[32 * ((b + 1) * 4 + i)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fma_4x2(acc, wreg[b * 4 + i][0], wreg[b * 4 + i][1], hb[b & 1][i]);
+            }
+        }
+        {
+            const bool b0 = ns & 1, b1 = ns & 2, b2 = ns & 4;
+            float wv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ux = rs_level<DPP_HMIRROR>(acc[e].x, acc[2 + e].x, b2);
+                const float uy = rs_level<DPP_HMIRROR>(acc[e].y, acc[2 + e].y, b2);
+                wv[e] = rs_level<DPP_XOR1>(ux, uy, b0);
+            }
+            const float z = rs_level<DPP_XOR2>(wv[0], wv[1], b1);    // the 8 n slices of this lane's group of 8 folded
+            const float v = z + dpp_f<DPP_ROR8>(z);                   // + the other group of 8 of the 16-lane row
+            dh_rec = v + __shfl_xor(v, 16);                           // + the other 16 slices
+        }
+    }
+    if (failed || flag[0]) {
+        if (tid == 0) atomicOr(p.status, 1u);
+        if (live) for (int tt = 0; tt < T; ++tt) p.DG[((size_t)row * T + tt) * G + unit] = __int_as_float(0x7fc00000);
+    }
+}
