@@ -51,6 +51,7 @@ bool i2l_gemm_split_bf16_ok(const GemmArgs& g);   // would i2l_gemm run this on 
 // ---- 3 x bf16 split conv block on the bf16 matrix cores (conv_bf16x3.hip); inference forward of blocks with
 //      Cin % 16 == 0 and Cout % 64 == 0 (shape test only: the caller decides on I2L_FLAG_EXACT_FP32)
 bool i2l_conv_bf16x3_applicable(int Cin, int Cout);
+bool i2l_conv_bf16x3_full_applicable(int Cin, int Cout);   // the full-resolution (data gradient) flavour: also Cout == 32
 size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout);
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
                         int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, int full = 0);

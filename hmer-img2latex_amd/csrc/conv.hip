@@ -405,7 +405,7 @@ extern "C" size_t i2l_conv_workspace_bytes(int Cin, int Cout) {
     const int cb = mfma_ci_blk(Cin), cob = mfma_co_blk(Cout);
     const int n_chunks = i2l_cdiv(Cin, cb), co_blocks = i2l_cdiv(Cout, cob);
     size_t need = i2l_align((size_t)co_blocks * n_chunks * (cb / 2) * 9 * 2 * cob * sizeof(float));
-    if (i2l_conv_bf16x3_applicable(Cin, Cout)) {
+    if (i2l_conv_bf16x3_full_applicable(Cin, Cout)) {
         const size_t n3 = i2l_conv_bf16x3_workspace_bytes(Cin, Cout);
         if (n3 > need) need = n3;
     }
@@ -419,7 +419,7 @@ int run_conv(bool pool, const float* x, const float* w, const float* bias, float
     const int Hp = H / 2, Wp = W / 2;
     // data gradient on the split-bf16 matrix-core kernel (fp32-grade, like the weight-gradient GEMMs) where the
     // channel counts and even H, W allow
-    if (!exact && !pool && !bias && !amax && ((H | W) & 1) == 0 && i2l_conv_bf16x3_applicable(Cin, Cout)) {
+    if (!exact && !pool && !bias && !amax && ((H | W) & 1) == 0 && i2l_conv_bf16x3_full_applicable(Cin, Cout)) {
         if (!workspace || workspace_bytes < i2l_conv_workspace_bytes(Cin, Cout)) return I2L_ERR_WORKSPACE;
         return i2l_conv_bf16x3_run(x, w, nullptr, y, nullptr, B, Cin, H, W, Cout, workspace, workspace_bytes, s, 1);
     }

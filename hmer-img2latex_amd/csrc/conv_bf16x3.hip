@@ -94,7 +94,8 @@ __global__ void conv_pack3_kernel(const float* __restrict__ w, bf16_t* __restric
 
 // FULL: plain full-resolution convolution (no bias / ReLU / pooling): the data gradient of a block, y is (B,Cout,H,W)
 // AM: also write the pooling arg max (training forward); a template parameter so that the inference kernel is unchanged
-template <int WX, bool FULL = false, bool AM = false>
+// NT: 32-channel MFMA column tiles per wave (2 = a 64-channel block; 1 = Cout == 32, FULL only: block 1's data gradient)
+template <int WX, bool FULL = false, bool AM = false, int NT = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wpack, const float* __restrict__ bias,
     float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
@@ -209,11 +210,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
         const int b = it / tiles_per_img, tl = it - b * tiles_per_img;
         const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
         const int y0 = ty * TL::TR, x0 = tx * TL::TC;
-        f32x16 acc[2][2];
+        f32x16 acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    bf16x8 a[2][3], bw[2][3];
+                    bf16x8 a[2][3], bw[NT][3];
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                             a[m][sp] = *reinterpret_cast<const bf16x8*>(&t);
                         }
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < NT; ++n)
 #pragma unroll
                         for (int sp = 0; sp < 3; ++sp) {
                             const uint4 t = w_s[b_base + ((kx * 3 + sp) * 2) * CO_BLK + n * 32];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
-                            for (int n = 0; n < 2; ++n)
+                            for (int n = 0; n < NT; ++n)
                                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][TI[t]], bw[n][TJ[t]], acc[m][n], 0, 0, 0);
                 }
             }
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
         const int py0 = y0 >> 1, px0 = x0 >> 1;
         if constexpr (FULL) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 const int co = cb * CO_BLK + n * 32 + i;
                 if (co >= Cout) continue;
 #pragma unroll
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
         if ((Wp & 3) == 0 && py0 + PR <= Hp && px0 + PC <= Wp && (cb + 1) * CO_BLK <= Cout) {
             // out_s was last read before the first barrier of this tile's first phase: free to overwrite
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 const float bv = bias[cb * CO_BLK + n * 32 + i];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
             continue;
         }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NT; ++n) {
             const int co = cb * CO_BLK + n * 32 + i;
             if (co >= Cout) continue;
             const float bv = bias[co];
@@ -519,9 +520,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
 bool i2l_conv_bf16x3_applicable(int Cin, int Cout) {
     return Cin % CH == 0 && Cout % CO_BLK == 0;
 }
+// the full-resolution (data gradient) flavour also takes Cout == 32: one MFMA column tile per wave, half a filter block
+bool i2l_conv_bf16x3_full_applicable(int Cin, int Cout) {
+    return Cin % CH == 0 && (Cout % CO_BLK == 0 || Cout == 32);
+}
 
 size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout) {
-    return i2l_align((size_t)(Cout / CO_BLK) * (Cin / CH) * W_SLAB_U4 * 16);
+    return i2l_align((size_t)((Cout + CO_BLK - 1) / CO_BLK) * (Cin / CH) * W_SLAB_U4 * 16);
 }
 
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
@@ -529,7 +534,8 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     if (full && ((H | W) & 1)) return I2L_ERR_UNSUPPORTED;       // full resolution is written quad by quad
     if (workspace_bytes < i2l_conv_bf16x3_workspace_bytes(Cin, Cout) || !workspace) return I2L_ERR_WORKSPACE;
     const int Hp = H / 2, Wp = W / 2;
-    const int n_chunks = Cin / CH, co_blocks = Cout / CO_BLK;
+    const int n_chunks = Cin / CH, co_blocks = (Cout + CO_BLK - 1) / CO_BLK;
+    if (Cout % CO_BLK != 0 && !(full && Cout == 32)) return I2L_ERR_UNSUPPORTED;
     bf16_t* wp = static_cast<bf16_t*>(workspace);
     const size_t total = (size_t)co_blocks * n_chunks * 9 * 2 * CO_BLK * 8;
     hipLaunchKernelGGL(conv_pack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout,
@@ -558,7 +564,10 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     dim3 grid((unsigned)(i2l_cdiv(walks, 8) * 8 * co_blocks));       // ids decoded in the kernel (XCD-aware)
 #define I2L_LAUNCH3(WXV)                                                                                              \
     do {                                                                                                              \
-        if (full)                                                                                                     \
+        if (full && Cout == 32)                                                                                       \
+            hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, true, false, 1>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+        else if (full)                                                                                                \
             hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, true>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y,  \
                                amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
         else if (amax)                                                                                                \
