@@ -604,10 +604,11 @@ TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
     o.gemm_ws_bytes = i2l_align(g);
     off += o.gemm_ws_bytes;
     if (L == 1 && H == 256) {           // grouped recurrences (train_group.inc.h): status block + exchange granules
-        // up to 128 rows: two rows per group (twice the groups, half the granules); above: four rows per group
-        o.n_groups = B <= 128 ? i2l_cdiv(B, 2) : i2l_cdiv(B, 4);
+        // rows per group: 1 up to 64 rows (all 256 CUs on a 64-row shard), 2 up to 128 rows, 4 above
+        o.n_groups = B <= 64 ? B : (B <= 128 ? i2l_cdiv(B, 2) : i2l_cdiv(B, 4));
         o.xchg = off;
-        o.xchg_bytes = 2048 + (size_t)i2l_cdiv(o.n_groups, 8) * 8 * 2 * 4 * (B <= 128 ? TGB2_GRAN : TGB_GRAN) * sizeof(u64_t);
+        o.xchg_bytes = 2048 + (size_t)i2l_cdiv(o.n_groups, 8) * 8 * 2 * 4 *
+                                  (B <= 64 ? TGB1_GRAN : (B <= 128 ? TGB2_GRAN : TGB_GRAN)) * sizeof(u64_t);
         off += i2l_align(o.xchg_bytes);
     }
     o.total = off;
@@ -716,9 +717,12 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
             gp.status = reinterpret_cast<unsigned*>(base + lo.xchg);
             gp.xchg = reinterpret_cast<u64_t*>(base + lo.xchg + 2048);
             gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
-            const size_t used = 2048 + (size_t)i2l_cdiv(lo.n_groups, 8) * 8 * 2 * 4 * (B <= 128 ? TGF2_GRAN : TGF_GRAN) * sizeof(u64_t);
+            const size_t used = 2048 + (size_t)i2l_cdiv(lo.n_groups, 8) * 8 * 2 * 4 *
+                                       (B <= 64 ? TGF1_GRAN : (B <= 128 ? TGF2_GRAN : TGF_GRAN)) * sizeof(u64_t);
             if (hipMemsetAsync(base + lo.xchg, 0, used, s) != hipSuccess) return I2L_ERR_LAUNCH;
-            if (B <= 128)
+            if (B <= 64)
+                hipLaunchKernelGGL(lstm_train_fwd_group1_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);
+            else if (B <= 128)
                 hipLaunchKernelGGL(lstm_train_fwd_group2_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);
             else
                 hipLaunchKernelGGL(lstm_train_fwd_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);
@@ -850,7 +854,9 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
             gp.xchg = reinterpret_cast<u64_t*>(base + lo.xchg + 2048);
             gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
             if (hipMemsetAsync(base + lo.xchg, 0, lo.xchg_bytes, s) != hipSuccess) return I2L_ERR_LAUNCH;
-            if (B <= 128)
+            if (B <= 64)
+                hipLaunchKernelGGL(lstm_train_bwd_group1_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);
+            else if (B <= 128)
                 hipLaunchKernelGGL(lstm_train_bwd_group2_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);
             else
                 hipLaunchKernelGGL(lstm_train_bwd_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);

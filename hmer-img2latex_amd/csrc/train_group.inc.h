@@ -566,3 +566,252 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group2_kernel(TrainGroupBw
         if (live) for (int tt = 0; tt < T; ++tt) p.DG[((size_t)row * T + tt) * G + unit] = __int_as_float(0x7fc00000);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ONE row per group (B <= 64: all 256 CUs work on BASELINE configs[3]'s 64 rows per GPU).  With a single row the
+// packed FMA has no second row to fill its upper half, so it is filled with a second k instead: a thread's weights are
+// stored as pairs {W[k0], W[k1]}, h (or dG) comes from LDS as the matching pair (the LDS image is permuted so that the
+// pair is one 8-byte read), an accumulator holds {sum over its k0s, sum over its k1s} and the halves are added before
+// the cross-lane fold.  Per step a thread issues 64 packed FMAs (two-row kernel: 128) and the exchanges halve again
+// (forward 64 h values, backward 256 gate gradients per member).  Summation order differs from the 2 / 4-row kernels
+// (k pairs), so results agree to fp32 rounding, not to the bit.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TGF1_GRAN = 64 + 32;             // forward: h granules [unit 64] + placement line (at 80)
+constexpr int TGB1_GRAN = 256 + 16;            // backward: gate-gradient granules [gate 4][unit 64] + placement (at 256)
+constexpr int DPP_SHL1 = 0x101, DPP_SHL5 = 0x105;
+
+__device__ __forceinline__ void pkfma(f32x2& acc, f32x2 a, f32x2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+__global__ __launch_bounds__(TGT) void lstm_train_fwd_group1_kernel(TrainGroupFwd p) {
+    // h image [parity][256]: h[k], k = 16 i + 8 s + ke, lives at ((i * 8 + ke) * 2 + s): a thread's pair (s = 0, 1) is adjacent
+    __shared__ __attribute__((aligned(16))) float h_s[2][256];
+    __shared__ int flag[4];
+    const int tid = threadIdx.x;
+    const int within = blockIdx.x & 31;
+    const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
+    if (group >= p.n_groups) return;
+    const int T = p.T;
+    const int row = group;                                 // n_groups == B
+    const int ul = tid >> 3, ke = tid & 7;
+    const int unit = 64 * m + ul;
+    constexpr int G = 1024, H = 256;
+    f32x2 wp[4][16];                                       // wp[gate][i] = {WhhT[16 i + ke][gate], WhhT[16 i + 8 + ke][gate]}
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 t0 = *reinterpret_cast<const float4*>(p.WhhT + (size_t)(16 * i + ke) * G + 4 * unit);
+        const float4 t1 = *reinterpret_cast<const float4*>(p.WhhT + (size_t)(16 * i + 8 + ke) * G + 4 * unit);
+        wp[0][i] = f32x2{t0.x, t1.x}; wp[1][i] = f32x2{t0.y, t1.y};
+        wp[2][i] = f32x2{t0.z, t1.z}; wp[3][i] = f32x2{t0.w, t1.w};
+    }
+    for (int idx = tid; idx < 2 * 256; idx += TGT) (&h_s[0][0])[idx] = 0.f;
+    u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGF1_GRAN;
+    const bool local = group_placement_local(xg, TGF1_GRAN, 80, m, flag) && !p.agent_scope;   // barrier inside: h_s zeroed
+    const bool live = ke == 0;                                                  // this lane owns the cell of `unit`
+    auto hpos = [](int k) { return (((k >> 4) * 8 + (k & 7)) << 1) + ((k >> 3) & 1); };
+    float c_own = 0.f, h_own = 0.f;
+    bool failed = false;
+    int t = 0;
+    for (; t < T; ++t) {
+        const size_t bt = (size_t)row * T + t;
+        const float4 gx = *reinterpret_cast<const float4*>(p.GX + bt * G + 4 * unit);
+        f32x2 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = splat2(0.f);
+        if (t > 0) {
+            const f32x2* hq2 = reinterpret_cast<const f32x2*>(h_s[t & 1]) + ke;      // pair i at hq2[8 i]
+            f32x2 hb[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hb[0][i] = hq2[8 * i];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hb[(b + 1) & 1][i] = hq2[8 * ((b + 1) * 4 + i)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pkfma(acc[g], wp[g][b * 4 + i], hb[b & 1][i]);
+            }
+        }
+        {
+            // halves, then the 8 k-slices: 4 -> 2 -> 1 value per lane (gate 2*(ke>>2) + (ke & 1)), then the two lane pairs add up
+            const bool b0 = ke & 1, b2 = ke & 4;
+            const float s0 = acc[0].x + acc[0].y, s1 = acc[1].x + acc[1].y, s2 = acc[2].x + acc[2].y, s3 = acc[3].x + acc[3].y;
+            const float u0 = rs_level<DPP_HMIRROR>(s0, s2, b2), u1 = rs_level<DPP_HMIRROR>(s1, s3, b2);
+            const float wv = rs_level<DPP_XOR1>(u0, u1, b0);
+            const float zi = wv + dpp_f<DPP_XOR2>(wv);
+            const float zf = dpp_f<DPP_SHL1>(zi), zg = dpp_f<DPP_SHL4>(zi), zo = dpp_f<DPP_SHL5>(zi);
+            const float ig = sigmoidf_(gx.x + zi), fg = sigmoidf_(gx.y + zf);
+            const float gg = tanhf(gx.z + zg), og = sigmoidf_(gx.w + zo);
+            const float h_prev = h_own;
+            c_own = fg * c_own + ig * gg;
+            h_own = og * tanhf(c_own);
+            if (live) {
+                *reinterpret_cast<float4*>(p.ACT + bt * G + 4 * unit) = make_float4(ig, fg, gg, og);
+                p.C[bt * H + unit] = c_own;
+                p.Hout[bt * H + unit] = h_own;
+                p.Hprev[bt * H + unit] = h_prev;
+            }
+        }
+        if (t + 1 == T) break;
+        const unsigned epoch = (unsigned)t + 1u;
+        u64_t* slot = xg + (size_t)(t & 1) * 4 * TGF1_GRAN;
+        if (live) store_granule(slot + (size_t)m * TGF1_GRAN + ul, granule(epoch, h_own), local);
+        {
+            const int gi = tid & 63, pi = min(tid >> 6, 2);
+            const int q = pi + (pi >= m ? 1 : 0);
+            const u64_t* pa_ = slot + (size_t)q * TGF1_GRAN + gi;
+            u64_t g0 = 0;
+            long long t_start = 0;
+            unsigned spins = 0;
+            if (tid < 192) {
+                for (;;) {
+                    g0 = load_granule(pa_);
+                    if ((unsigned)(g0 >> 32) == epoch) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0) {
+                        const long long now = (long long)wall_clock64();
+                        if (t_start == 0) t_start = now;
+                        else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
+                    }
+                }
+            }
+            float* hn = h_s[(t + 1) & 1];
+            if (tid < 192) hn[hpos(64 * q + gi)] = __uint_as_float((unsigned)g0);
+            if (live) hn[hpos(64 * m + ul)] = h_own;
+        }
+        if (failed) flag[0] = 1;
+        __syncthreads();
+        if (flag[0]) { failed = true; break; }
+    }
+    if (failed || flag[0]) {
+        if (tid == 0) atomicOr(p.status, 1u);
+        if (live) for (int tt = 0; tt < T; ++tt) p.Hout[((size_t)row * T + tt) * H + unit] = __int_as_float(0x7fc00000);
+    }
+}
+
+__global__ __launch_bounds__(TGT) void lstm_train_bwd_group1_kernel(TrainGroupBwd p) {
+    // gate-gradient image [parity][1024]: dG[n], n = 64 i + 32 s + ns, lives at ((i * 32 + ns) * 2 + s)
+    __shared__ __attribute__((aligned(16))) float dgs[2][1024];
+    __shared__ int flag[4];
+    const int tid = threadIdx.x;
+    const int within = blockIdx.x & 31;
+    const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
+    if (group >= p.n_groups) return;
+    const int T = p.T;
+    const int row = group;
+    constexpr int G = 1024, H = 256;
+    // product: thread = (unit quad jq, n slice ns): dh[4 units] += Whh[64 i + 32 s + ns][units] dG[..], pairs over s
+    const int jq = tid >> 5, ns = tid & 31;
+    f32x2 wp[4][16];                                       // wp[unit][i] = {Whh[64 i + ns][unit], Whh[64 i + 32 + ns][unit]}
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 t0 = *reinterpret_cast<const float4*>(p.Whh + (size_t)(64 * i + ns) * H + 64 * m + 4 * jq);
+        const float4 t1 = *reinterpret_cast<const float4*>(p.Whh + (size_t)(64 * i + 32 + ns) * H + 64 * m + 4 * jq);
+        wp[0][i] = f32x2{t0.x, t1.x}; wp[1][i] = f32x2{t0.y, t1.y};
+        wp[2][i] = f32x2{t0.z, t1.z}; wp[3][i] = f32x2{t0.w, t1.w};
+    }
+    // after the fold every lane of a group of 8 holds dh of unit 4 jq + o_col, o_col = 2*(ns>>2 & 1) + (ns & 1); the lanes
+    // ns in {0, 1, 4, 5} run the cell backward for their unit
+    const int o_col = ((ns >> 2) & 1) * 2 + (ns & 1);
+    const int ul = 4 * jq + o_col, unit = 64 * m + ul;
+    const bool owner = (ns & ~5) == 0;
+    auto dpos = [](int n) { return (((n >> 6) * 32 + (n & 31)) << 1) + ((n >> 5) & 1); };
+    u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGB1_GRAN;
+    const bool local = group_placement_local(xg, TGB1_GRAN, 256, m, flag) && !p.agent_scope;
+    float dh_rec = 0.f, dc_next = 0.f;
+    bool failed = false;
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        const unsigned epoch = (unsigned)(T - t);
+        const size_t bt = (size_t)row * T + t;
+        u64_t* slot = xg + (size_t)par * 4 * TGB1_GRAN;
+        float* dcur = dgs[par];
+        if (owner) {
+            const float4 a = *reinterpret_cast<const float4*>(p.ACT + bt * G + 4 * unit);
+            const float c = p.C[bt * H + unit];
+            const float cp = t > 0 ? p.C[(bt - 1) * H + unit] : 0.f;
+            const float dh = dh_rec + p.dHtop[bt * H + unit];
+            const float tc = tanhf(c);
+            const float d_o = dh * tc * a.w * (1.f - a.w);
+            const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
+            const float d_i = dc * a.z * a.x * (1.f - a.x);
+            const float d_f = dc * cp * a.y * (1.f - a.y);
+            const float d_g = dc * a.x * (1.f - a.z * a.z);
+            dc_next = dc * a.y;
+            const float dgv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                p.DG[bt * G + g * H + unit] = dgv[g];
+                dcur[dpos(g * 256 + 64 * m + ul)] = dgv[g];
+                if (t > 0) store_granule(slot + (size_t)m * TGB1_GRAN + g * 64 + ul, granule(epoch, dgv[g]), local);
+            }
+        }
+        if (t == 0) break;
+        {
+            // 3 peers x 256 granules = 768: thread tid fetches granule tid & 255 of peer tid >> 8 (0, 1) and, below 256, of peer 2
+            const int e = tid & 255;
+            const int qa = (tid >> 8) + ((tid >> 8) >= m ? 1 : 0), qb = 2 + (2 >= m ? 1 : 0);
+            u64_t ga, gb = 0;
+            long long t_start = 0;
+            unsigned spins = 0;
+            for (;;) {
+                ga = load_granule(slot + (size_t)qa * TGB1_GRAN + e);
+                bool ok = (unsigned)(ga >> 32) == epoch;
+                if (tid < 256) { gb = load_granule(slot + (size_t)qb * TGB1_GRAN + e); ok = ok && (unsigned)(gb >> 32) == epoch; }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255u) == 0) {
+                    const long long now = (long long)wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
+                }
+            }
+            // granule e = g*64 + ul' of member q  ->  gate row n = g*256 + 64 q + ul'
+            dcur[dpos((e >> 6) * 256 + 64 * qa + (e & 63))] = __uint_as_float((unsigned)ga);
+            if (tid < 256) dcur[dpos((e >> 6) * 256 + 64 * qb + (e & 63))] = __uint_as_float((unsigned)gb);
+        }
+        if (failed) flag[0] = 1;
+        __syncthreads();
+        if (flag[0]) { failed = true; break; }
+        // dh_{t-1}[own units] = sum_n Whh[n][unit] dG[n]
+        f32x2 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = splat2(0.f);
+        {
+            const f32x2* dq2 = reinterpret_cast<const f32x2*>(dcur) + ns;        // pair i at dq2[32 i]
+            f32x2 hb[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hb[0][i] = dq2[32 * i];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hb[(b + 1) & 1][i] = dq2[32 * ((b + 1) * 4 + i)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pkfma(acc[u], wp[u][b * 4 + i], hb[b & 1][i]);
+            }
+        }
+        {
+            const bool b0 = ns & 1, b2 = ns & 4;
+            const float s0 = acc[0].x + acc[0].y, s1 = acc[1].x + acc[1].y, s2 = acc[2].x + acc[2].y, s3 = acc[3].x + acc[3].y;
+            const float u0 = rs_level<DPP_HMIRROR>(s0, s2, b2), u1 = rs_level<DPP_HMIRROR>(s1, s3, b2);
+            const float wv = rs_level<DPP_XOR1>(u0, u1, b0);
+            const float z = wv + dpp_f<DPP_XOR2>(wv);                 // the 8 n slices of this lane's group of 8
+            const float v = z + dpp_f<DPP_ROR8>(z);                   // + the other group of 8 of the 16-lane row
+            dh_rec = v + __shfl_xor(v, 16);                           // + the other 16 slices
+        }
+    }
+    if (failed || flag[0]) {
+        if (tid == 0) atomicOr(p.status, 1u);
+        if (owner) for (int tt = 0; tt < T; ++tt) p.DG[((size_t)row * T + tt) * G + unit] = __int_as_float(0x7fc00000);
+    }
+}

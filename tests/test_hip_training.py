@@ -41,11 +41,11 @@ def build(name):
     return d, cfg, m.to(DEV)
 
 
-@pytest.mark.parametrize("name,batch", [(n, 4) for n in SMALL + ["primary"]] + [("primary", 7), ("primary", 1), ("primary", 130)])
+@pytest.mark.parametrize("name,batch", [(n, 4) for n in SMALL + ["primary"]] + [("primary", 7), ("primary", 1), ("primary", 70), ("primary", 130)])
 def test_decoder_backward_vs_oracle(name, batch):
     """d(loss)/d(decoder params) and d(loss)/d(enc) for the teacher-forced decoder, dropout 0.  The primary config
-    runs the grouped recurrences: up to 128 rows as 4 workgroups per TWO rows (batch 7 and 1 leave a group with a missing
-    row), above that 4 workgroups per FOUR rows (batch 130: 33 groups, the last with two missing rows)."""
+    runs the grouped recurrences: 4 workgroups per ONE row up to 64 rows (batches 1, 4, 7), per TWO rows up to 128 (batch
+    70), per FOUR rows above (batch 130: 33 groups, the last with two missing rows)."""
     d, cfg, m = build(name)
     sd = torch_state_dict(name)
     T = 12
