@@ -18,11 +18,17 @@ namespace {
 
 constexpr int SQ_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n,
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, size_t n4,
                                                             double* __restrict__ partial) {
     __shared__ double red[256];
     double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    // n4 = number of 16-byte pieces read as such (0 when the buffer is not 16-byte aligned); the rest element by element
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const double v = g[i];
         s += v * v;
     }
@@ -108,7 +114,8 @@ extern "C" int i2l_grad_clip_adam_step(float* params, const float* grads, float*
     float* coefs = reinterpret_cast<float*>(tail + 16);
     size_t nb = (n + 255) / 256;
     const int nblk = (int)(nb > (size_t)SQ_BLOCKS ? SQ_BLOCKS : nb);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, s, grads, n, partial);
+    const size_t n4 = reinterpret_cast<uintptr_t>(grads) % 16 == 0 ? n / 4 : 0;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, s, grads, n, n4, partial);
     I2L_CHECK_LAUNCH();
     hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, nblk, count_ptr, max_norm,
                        stats_out, skipped, step, lr, beta1, beta2, coefs);
