@@ -146,7 +146,10 @@ def test_encoder_backward_vs_oracle(name, variant):
 def test_conv_bwd_odd_shapes():
     torch.manual_seed(2)
     L = _lib.lib()
-    for (B, Cin, H, W, Cout) in [(2, 3, 7, 9, 5), (3, 5, 16, 70, 9), (2, 8, 12, 20, 32), (1, 32, 16, 48, 64), (2, 33, 9, 11, 96)]:
+    for (B, Cin, H, W, Cout) in [(2, 3, 7, 9, 5), (3, 5, 16, 70, 9), (2, 8, 12, 20, 32), (1, 32, 16, 48, 64), (2, 33, 9, 11, 96),
+                                 # the dedicated weight-gradient kernel (Cin % 32 == 0, Cout % 64 == 0, W % 16 == 0): one and
+                                 # four channel-block combinations, strips shorter / longer than a workgroup's run, H = 2
+                                 (4, 32, 32, 160, 64), (3, 64, 16, 80, 128), (16, 32, 10, 32, 64), (40, 64, 2, 64, 64)]:
         x = torch.randn(B, Cin, H, W, requires_grad=True)
         w = (torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)).requires_grad_(True)
         b = torch.randn(Cout, requires_grad=True)
