@@ -91,9 +91,11 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group_kernel(TrainGroupFwd
     float c_own = 0.f, h_own = 0.f;
     bool failed = false;
     int t = 0;
+    float4 gx_next = *reinterpret_cast<const float4*>(p.GX + (size_t)row * T * G + 4 * unit);     // one step ahead, as in group1
     for (; t < T; ++t) {
         const size_t bt = (size_t)row * T + t;
-        const float4 gx = *reinterpret_cast<const float4*>(p.GX + bt * G + 4 * unit);
+        const float4 gx = gx_next;
+        if (t + 1 < T) gx_next = *reinterpret_cast<const float4*>(p.GX + (bt + 1) * G + 4 * unit);
         f32x2 acc[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) { acc[g][0] = splat2(0.f); acc[g][1] = splat2(0.f); }
@@ -207,17 +209,28 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group_kernel(TrainGroupBwd
     const bool local = group_placement_local(xg, TGB_GRAN, 1024, m, flag) && !p.agent_scope;
     float dh_rec = 0.f, dc_next = 0.f;
     bool failed = false;
+    float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f);                             // step t-1's reads, requested during step t
+    float c_nx = 0.f, cp_nx = 0.f, dht_nx = 0.f;
+    auto prefetch = [&](int tt) {
+        if (!owner || tt < 0) return;
+        const size_t b2 = (size_t)row * T + tt;
+        a_nx = *reinterpret_cast<const float4*>(p.ACT + b2 * G + 4 * unit);
+        c_nx = p.C[b2 * H + unit];
+        cp_nx = tt > 0 ? p.C[(b2 - 1) * H + unit] : 0.f;
+        dht_nx = p.dHtop[b2 * H + unit];
+    };
+    prefetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
         const unsigned epoch = (unsigned)(T - t);
         const size_t bt = (size_t)row * T + t;
         u64_t* slot = xg + (size_t)par * 4 * TGB_GRAN;
         float* dcur = dgs[par];
+        const float4 a = a_nx;
+        const float c = c_nx, cp = cp_nx, dht = dht_nx;
+        prefetch(t - 1);
         if (owner) {
-            const float4 a = *reinterpret_cast<const float4*>(p.ACT + bt * G + 4 * unit);
-            const float c = p.C[bt * H + unit];
-            const float cp = t > 0 ? p.C[(bt - 1) * H + unit] : 0.f;
-            const float dh = dh_rec + p.dHtop[bt * H + unit];
+            const float dh = dh_rec + dht;
             const float tc = tanhf(c);
             const float d_o = dh * tc * a.w * (1.f - a.w);
             const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
@@ -359,9 +372,11 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group2_kernel(TrainGroupFw
     float c_own = 0.f, h_own = 0.f;
     bool failed = false;
     int t = 0;
+    float4 gx_next = *reinterpret_cast<const float4*>(p.GX + (size_t)row * T * G + 4 * unit);     // one step ahead, as in group1
     for (; t < T; ++t) {
         const size_t bt = (size_t)row * T + t;
-        const float4 gx = *reinterpret_cast<const float4*>(p.GX + bt * G + 4 * unit);
+        const float4 gx = gx_next;
+        if (t + 1 < T) gx_next = *reinterpret_cast<const float4*>(p.GX + (bt + 1) * G + 4 * unit);
         f32x2 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = splat2(0.f);
@@ -470,17 +485,28 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group2_kernel(TrainGroupBw
     const bool local = group_placement_local(xg, TGB2_GRAN, 512, m, flag) && !p.agent_scope;
     float dh_rec = 0.f, dc_next = 0.f;
     bool failed = false;
+    float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f);                             // step t-1's reads, requested during step t
+    float c_nx = 0.f, cp_nx = 0.f, dht_nx = 0.f;
+    auto prefetch = [&](int tt) {
+        if (!owner || tt < 0) return;
+        const size_t b2 = (size_t)row * T + tt;
+        a_nx = *reinterpret_cast<const float4*>(p.ACT + b2 * G + 4 * unit);
+        c_nx = p.C[b2 * H + unit];
+        cp_nx = tt > 0 ? p.C[(b2 - 1) * H + unit] : 0.f;
+        dht_nx = p.dHtop[b2 * H + unit];
+    };
+    prefetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
         const unsigned epoch = (unsigned)(T - t);
         const size_t bt = (size_t)row * T + t;
         u64_t* slot = xg + (size_t)par * 4 * TGB2_GRAN;
         float* dcur = dgs[par];
+        const float4 a = a_nx;
+        const float c = c_nx, cp = cp_nx, dht = dht_nx;
+        prefetch(t - 1);
         if (owner) {
-            const float4 a = *reinterpret_cast<const float4*>(p.ACT + bt * G + 4 * unit);
-            const float c = p.C[bt * H + unit];
-            const float cp = t > 0 ? p.C[(bt - 1) * H + unit] : 0.f;
-            const float dh = dh_rec + p.dHtop[bt * H + unit];
+            const float dh = dh_rec + dht;
             const float tc = tanhf(c);
             const float d_o = dh * tc * a.w * (1.f - a.w);
             const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
@@ -613,9 +639,13 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group1_kernel(TrainGroupFw
     float c_own = 0.f, h_own = 0.f;
     bool failed = false;
     int t = 0;
+    // the input-side gates of step t+1 are requested at the top of step t: with one row per group the recurrent product is
+    // only ~0.2 us, far too short to hide an HBM round trip behind
+    float4 gx_next = *reinterpret_cast<const float4*>(p.GX + (size_t)row * T * G + 4 * unit);
     for (; t < T; ++t) {
         const size_t bt = (size_t)row * T + t;
-        const float4 gx = *reinterpret_cast<const float4*>(p.GX + bt * G + 4 * unit);
+        const float4 gx = gx_next;
+        if (t + 1 < T) gx_next = *reinterpret_cast<const float4*>(p.GX + (bt + 1) * G + 4 * unit);
         f32x2 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = splat2(0.f);
@@ -725,17 +755,29 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group1_kernel(TrainGroupBw
     const bool local = group_placement_local(xg, TGB1_GRAN, 256, m, flag) && !p.agent_scope;
     float dh_rec = 0.f, dc_next = 0.f;
     bool failed = false;
+    // what the cell backward of step t-1 reads (activations, cell states, dh from above) is requested during step t
+    float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c_nx = 0.f, cp_nx = 0.f, dht_nx = 0.f;
+    auto prefetch = [&](int tt) {
+        if (!owner || tt < 0) return;
+        const size_t b2 = (size_t)row * T + tt;
+        a_nx = *reinterpret_cast<const float4*>(p.ACT + b2 * G + 4 * unit);
+        c_nx = p.C[b2 * H + unit];
+        cp_nx = tt > 0 ? p.C[(b2 - 1) * H + unit] : 0.f;
+        dht_nx = p.dHtop[b2 * H + unit];
+    };
+    prefetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const int par = t & 1;
         const unsigned epoch = (unsigned)(T - t);
         const size_t bt = (size_t)row * T + t;
         u64_t* slot = xg + (size_t)par * 4 * TGB1_GRAN;
         float* dcur = dgs[par];
+        const float4 a = a_nx;
+        const float c = c_nx, cp = cp_nx, dht = dht_nx;
+        prefetch(t - 1);
         if (owner) {
-            const float4 a = *reinterpret_cast<const float4*>(p.ACT + bt * G + 4 * unit);
-            const float c = p.C[bt * H + unit];
-            const float cp = t > 0 ? p.C[(bt - 1) * H + unit] : 0.f;
-            const float dh = dh_rec + p.dHtop[bt * H + unit];
+            const float dh = dh_rec + dht;
             const float tc = tanhf(c);
             const float d_o = dh * tc * a.w * (1.f - a.w);
             const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
