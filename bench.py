@@ -339,6 +339,7 @@ def beside_paths(model, cfg, images, B, T, reps):
     toks = sum(len(r) - 1 for r in seqs)
     out["inference_api"] = {"tokens_per_s": round(toks / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
                             "includes": "encoder, greedy search, ids device->host, List[List[int]] building"}
+    out["host_images"] = host_image_path(model, images, B, T, reps)
     vocab = {"<PAD>": 0, "<START>": 1, "<END>": 2, "<UNK>": 3}
     vocab.update({f"t{i}": i for i in range(4, cfg["vocab_size"])})
     pred = Predictor(model, TokenTable(vocab, max_sequence_length=T), device=images.device)
@@ -368,6 +369,63 @@ def beside_paths(model, cfg, images, B, T, reps):
                              "includes": "host resize plans + upload of ragged uint8 pages, preprocess, encoder, decode "
                                          f"({T} steps, sticky stop), id compaction, sequence statistics, float64 scores"}
     return out
+
+
+def host_image_path(model, images, B, T, reps):
+    """The PCIe-inclusive rate of the headline workload: the fp32 pixels start in (pinned) host memory every batch, as
+    they do behind the reference's DataLoader (dataset.py:456-464).  The upload of batch i+1 runs on a copy stream into
+    the second of two device buffers while batch i is encoded and decoded; the ids go back to pinned host memory on a
+    third stream (on the compute stream that small copy would queue behind the next 63 MB upload in the DMA engine and
+    hold the next encoder back: 2.1 instead of 1.4 ms per batch)."""
+    dev = images.device
+    host = images.cpu().pin_memory()
+    bufs = [torch.empty_like(images) for _ in range(2)]
+    ids_host = [torch.empty(B, T, dtype=torch.int32).pin_memory() for _ in range(2)]
+    up_s, down_s, main_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        with torch.cuda.stream(up_s):
+            up_s.wait_event(consumed[i & 1])
+            bufs[i & 1].copy_(host, non_blocking=True)
+            uploaded[i & 1].record(up_s)
+
+    def run(n):
+        for e in consumed:
+            e.record(main_s)
+        upload(0)
+        for i in range(n):
+            if i + 1 < n:
+                upload(i + 1)
+            main_s.wait_event(uploaded[i & 1])
+            enc = model.encoder(bufs[i & 1])
+            ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
+            consumed[i & 1].record(main_s)
+            with torch.cuda.stream(down_s):
+                down_s.wait_event(consumed[i & 1])
+                ids_host[i & 1].copy_(ids, non_blocking=True)
+                ids.record_stream(down_s)
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        run(30)                 # the runtime's copy queues and signal pools settle over the first ~20 batches (2-4 ms hiccups)
+        n = max(reps, 40)
+        t0 = time.perf_counter()
+        run(n)
+        dt = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for _ in range(5):
+            bufs[0].copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        up = (time.perf_counter() - t0) / 5
+    for h in ids_host:
+        _lib.check_ids(h)
+    mb = host.numel() * 4 / 1e6
+    return {"tokens_per_s": round(B * T / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+            "upload_alone_ms": round(up * 1e3, 3), "upload_gb_per_s": round(mb / up / 1e3, 1),
+            "includes": f"{mb:.0f} MB of fp32 pixels from pinned host memory per batch (two device buffers, upload stream), "
+                        "encoder, greedy search, ids device->host (download stream)"}
 
 
 def extra_modes(args, world, rank, dev, dist):
