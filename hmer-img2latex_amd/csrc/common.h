@@ -59,4 +59,7 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
 // first conv block (Cin <= 3): whole K in one or two bf16 k-steps, filters in registers, im2col image in LDS
 bool i2l_conv_smallk_applicable(int Cin, int Cout);
 int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
-                        int H, int W, int Cout, hipStream_t s);
+                        int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s);
+// amax != NULL (training forward): both split kernels list the pooling windows whose arg max / ReLU decision is a
+// near-tie and re-evaluate them in fp32; the list lives in the workspace (after the packed weights of the bf16x3 kernel)
+size_t i2l_conv_fixlist_bytes(void);

@@ -7,7 +7,7 @@
 // relative error class as an fp32 fmaf chain (the dropped terms are <= 2^-24 |a||b|), while the bf16 MFMA
 // runs at 16x the fp32 MFMA rate: 6 MFMAs replace 8 for every 16 k, at 1/2 the cycles each -> 2.7x faster
 // than the exact-fp32 kernel of conv.hip.  It is NOT bit-identical to an fp32 fmaf chain; results stay within
-// the encoder tolerance (1e-5 relative, tests/test_hip_parity.py).  I2L_CONV_EXACT_FP32=1 selects conv.hip's
+// the encoder tolerance (1e-5 relative, tests/test_hip_parity.py).  I2L_FLAG_EXACT_FP32 selects conv.hip's
 // exact kernel instead.
 //
 // Tiling is the one of conv.hip: MFMA row i = 4*pp + 2*dy + dx (whole 2x2 pooling quads per lane), column =
@@ -69,11 +69,42 @@ template <int WX> struct Tile3 {
     static constexpr int IN_U4 = 3 * IR * ROW16;        // 16-byte pieces of the input image
 };
 
+// Training forward on split products (AM kernels).  The backward pass branches on two discrete facts of every pooling
+// window -- which of its four conv outputs is largest (first maximum wins, as ATen) and whether the pooled value
+// passes the ReLU -- and the split products (|err| ~ 1e-6 relative) could decide a near-tie differently from an fp32
+// evaluation.  So a window whose runner-up is within 2^-13 of the maximum, or whose pre-activation is that close to
+// zero, is put on a list (fix[0] = count, entries from fix[FIX_HDR]) and conv_pool_fixup_kernel re-evaluates just
+// those windows with fp32 FMAs: the decisions are then those of an fp32 computation (~1e-4 of the windows are
+// listed).  Exact ties are not listed: equal inputs give equal outputs in either arithmetic and the first index wins.
+constexpr unsigned FIX_HDR = 64;                 // list header, in entries (256 bytes)
+constexpr unsigned FIX_CAP = 1u << 20;           // capacity of the list (entries past it stay as computed)
+constexpr float FIX_TOL = 0x1p-13f;
+
+__device__ __forceinline__ void pool_window(float a0, float a1, float a2, float a3, float bv, float& outv, int& bi, bool& near) {
+    float best = a0;
+    bi = 0;
+    if (a1 > best) { best = a1; bi = 1; }
+    if (a2 > best) { best = a2; bi = 2; }
+    if (a3 > best) { best = a3; bi = 3; }
+    const float pre = best + bv;
+    outv = fmaxf(pre, 0.f);
+    const float scale = fmaxf(fmaxf(fabsf(best), fabsf(bv)), 1e-30f);
+    const float thr = FIX_TOL * scale;
+    const float d0 = best - a0, d1 = best - a1, d2 = best - a2, d3 = best - a3;
+    const bool tie = (d0 > 0.f && d0 <= thr) || (d1 > 0.f && d1 <= thr) || (d2 > 0.f && d2 <= thr) || (d3 > 0.f && d3 <= thr);
+    near = fabsf(pre) <= thr || (tie && pre > 0.f);
+}
+__device__ __forceinline__ void fix_append(unsigned* fix, size_t o) {
+    const unsigned at = atomicAdd(fix, 1u);
+    if (at < FIX_CAP) fix[FIX_HDR + at] = (unsigned)o;
+}
+
 // wpack3[cb][chunk][tap][split][lh][co 64][8] = split_s( w[cb*64+co][chunk*16 + 8*lh + j][tap] )
 // flip != 0: filter of the DATA-GRADIENT convolution, element = w[ci][co][2-ky][2-kx] of the forward filter w
 __global__ void conv_pack3_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cin, int Cout, int n_chunks,
-                                  size_t total, int flip) {
+                                  size_t total, int flip, unsigned* __restrict__ fix) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (.., co, j) of split 0
+    if (idx == 0 && fix) fix[0] = 0;                                        // empty near-decision list for the conv launch
     if (idx >= total) return;
     size_t r = idx;
     const int j = (int)(r % 8); r /= 8;
@@ -99,7 +130,7 @@ template <int WX, bool FULL = false, bool AM = false, int NT = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wpack, const float* __restrict__ bias,
     float* __restrict__ y, unsigned char* __restrict__ amax, int Cin, int H, int W, int Cout, int Hp, int Wp,
-    int tiles_x, int n_chunks, int tiles_per_img, int n_items, int items_per_wg) {
+    int tiles_x, int n_chunks, int tiles_per_img, int n_items, int items_per_wg, unsigned* __restrict__ fix) {
     typedef Tile3<WX> TL;
     constexpr int PR = TL::TR / 2, PC = TL::TC / 2;
     __shared__ __attribute__((aligned(16))) uint4 in_s[TL::IN_U4];
@@ -297,13 +328,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                     for (int q = 0; q < 4; ++q) {
                         const int pos = (wy * 2 + m) * PC + wx * 8 + 2 * q + h;
                         if constexpr (AM) {                  // training forward: first maximum wins, as ATen's max_pool2d
-                            float best = acc[m][n][4 * q];
-                            int bi = 0;
-#pragma unroll
-                            for (int e = 1; e < 4; ++e)
-                                if (acc[m][n][4 * q + e] > best) { best = acc[m][n][4 * q + e]; bi = e; }
-                            out_s[(n * 32 + i) * 65 + pos] = fmaxf(best + bv, 0.f);
+                            float ov;
+                            int bi;
+                            bool near;
+                            pool_window(acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3], bv, ov, bi, near);
+                            out_s[(n * 32 + i) * 65 + pos] = ov;
                             am_s[(n * 32 + i) * 68 + pos] = (unsigned char)bi;
+                            if (near && fix)
+                                fix_append(fix, (((size_t)b * Cout + cb * CO_BLK + n * 32 + i) * Hp + py0 + wy * 2 + m) * Wp + px0 + wx * 8 + 2 * q + h);
                         } else {
                             const float v = fmaxf(fmaxf(acc[m][n][4 * q], acc[m][n][4 * q + 1]),
                                                   fmaxf(acc[m][n][4 * q + 2], acc[m][n][4 * q + 3])) + bv;
@@ -335,14 +367,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int px = px0 + wx * 8 + 2 * q + h;
-                    float best = acc[m][n][4 * q];
-                    int bi = 0;
-#pragma unroll
-                    for (int e = 1; e < 4; ++e)
-                        if (acc[m][n][4 * q + e] > best) { best = acc[m][n][4 * q + e]; bi = e; }
+                    float ov;
+                    int bi;
+                    bool near;
+                    pool_window(acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3], bv, ov, bi, near);
                     if (px < Wp) {
-                        y[rowoff + px] = fmaxf(best + bv, 0.f);
+                        y[rowoff + px] = ov;
                         if (amax) amax[rowoff + px] = (unsigned char)bi;
+                        if (AM && near && fix) fix_append(fix, rowoff + px);
                     }
                 }
             }
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 template <int CIN, bool AM = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    unsigned char* __restrict__ amax, int H, int W, int Cout, int Hp, int Wp, int tiles_x) {
+    unsigned char* __restrict__ amax, int H, int W, int Cout, int Hp, int Wp, int tiles_x, unsigned* __restrict__ fix) {
     constexpr int RS = 48;                                   // pixels per patch row: rows r, r+1 half a bank row apart
     constexpr int PLANE = 10 * RS;                           // pixels per split plane
     __shared__ __attribute__((aligned(16))) uint2 img[3 * PLANE];
@@ -480,13 +512,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
             for (int q = 0; q < 4; ++q) {
                 const int pos = (wy * 2 + m) * 16 + wx * 8 + 2 * q + h;
                 if constexpr (AM) {                          // first maximum wins, as ATen's max_pool2d
-                    float best = acc[m][4 * q];
-                    int bi = 0;
-#pragma unroll
-                    for (int e = 1; e < 4; ++e)
-                        if (acc[m][4 * q + e] > best) { best = acc[m][4 * q + e]; bi = e; }
-                    out_s[i * 65 + pos] = fmaxf(best + bv, 0.f);
+                    float ov;
+                    int bi;
+                    bool near;
+                    pool_window(acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3], bv, ov, bi, near);
+                    out_s[i * 65 + pos] = ov;
                     am_s[i * 68 + pos] = (unsigned char)bi;
+                    const int fpy = (y0 >> 1) + wy * 2 + m, fpx = tx * 16 + wx * 8 + 2 * q + h;
+                    if (near && fix && cb * 32 + i < Cout && fpy < Hp && fpx < Wp)
+                        fix_append(fix, (((size_t)b * Cout + cb * 32 + i) * Hp + fpy) * Wp + fpx);
                 } else {
                     const float v = fmaxf(fmaxf(acc[m][4 * q], acc[m][4 * q + 1]), fmaxf(acc[m][4 * q + 2], acc[m][4 * q + 3])) + bv;
                     out_s[i * 65 + pos] = fmaxf(v, 0.f);
@@ -515,6 +549,55 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
     }
 }
 
+// One wave per listed window: the four conv outputs again with fp32 FMAs (lanes over input channels, butterfly sum),
+// then bias / ReLU / first maximum exactly as the fused epilogues.
+__global__ __launch_bounds__(256) void conv_pool_fixup_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              unsigned char* __restrict__ amax, const unsigned* __restrict__ fix,
+                                                              int Cin, int H, int W, int Cout, int Hp, int Wp) {
+    const unsigned n = min(fix[0], FIX_CAP);
+    const int lane = threadIdx.x & 63;
+    for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+        const unsigned o = fix[FIX_HDR + e];
+        const int px = (int)(o % Wp), py = (int)((o / Wp) % Hp);
+        const int co = (int)((o / ((unsigned)Wp * Hp)) % Cout), b = (int)(o / ((unsigned)Wp * Hp * Cout));
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ci = lane; ci < Cin; ci += 64) {
+            const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+            const float* wp = w + ((size_t)co * Cin + ci) * 9;
+            float win[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int iy = 2 * py - 1 + r, ix = 2 * px - 1 + c;
+                    win[r][c] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xp[(size_t)iy * W + ix] : 0.f;
+                }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = wp[ky * 3 + kx];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s[q] = fmaf(win[(q >> 1) + ky][(q & 1) + kx], wv, s[q]);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s[q] += __shfl_xor(s[q], off);
+        if (lane == 0) {
+            float best = s[0];
+            int bi = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (s[q] > best) { best = s[q]; bi = q; }
+            y[o] = fmaxf(best + bias[co], 0.f);
+            amax[o] = (unsigned char)bi;
+        }
+    }
+}
+
 }  // namespace
 
 bool i2l_conv_bf16x3_applicable(int Cin, int Cout) {
@@ -528,18 +611,33 @@ bool i2l_conv_bf16x3_full_applicable(int Cin, int Cout) {
 size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout) {
     return i2l_align((size_t)((Cout + CO_BLK - 1) / CO_BLK) * (Cin / CH) * W_SLAB_U4 * 16);
 }
+// near-decision list of the training forward (both split kernels): header + FIX_CAP entries
+size_t i2l_conv_fixlist_bytes(void) { return i2l_align((size_t)(FIX_HDR + FIX_CAP) * sizeof(unsigned)); }
+
+namespace {
+int launch_fixup(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, const unsigned* fix,
+                 int B, int Cin, int H, int W, int Cout, hipStream_t s) {
+    if ((size_t)B * Cout * (H / 2) * (W / 2) > 0xffffffffull) return I2L_ERR_UNSUPPORTED;     // entries are 32-bit offsets
+    hipLaunchKernelGGL(conv_pool_fixup_kernel, dim3(512), dim3(256), 0, s, x, w, bias, y, amax, fix, Cin, H, W, Cout, H / 2, W / 2);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+}  // namespace
 
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
                         int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, int full) {
     if (full && ((H | W) & 1)) return I2L_ERR_UNSUPPORTED;       // full resolution is written quad by quad
-    if (workspace_bytes < i2l_conv_bf16x3_workspace_bytes(Cin, Cout) || !workspace) return I2L_ERR_WORKSPACE;
+    const size_t pack_bytes = i2l_conv_bf16x3_workspace_bytes(Cin, Cout);
+    if (workspace_bytes < pack_bytes + (amax ? i2l_conv_fixlist_bytes() : 0) || !workspace) return I2L_ERR_WORKSPACE;
+    unsigned* fix = amax ? reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + pack_bytes) : nullptr;
+    if (amax && (size_t)B * Cout * (H / 2) * (W / 2) > 0xffffffffull) return I2L_ERR_UNSUPPORTED;
     const int Hp = H / 2, Wp = W / 2;
     const int n_chunks = Cin / CH, co_blocks = (Cout + CO_BLK - 1) / CO_BLK;
     if (Cout % CO_BLK != 0 && !(full && Cout == 32)) return I2L_ERR_UNSUPPORTED;
     bf16_t* wp = static_cast<bf16_t*>(workspace);
     const size_t total = (size_t)co_blocks * n_chunks * 9 * 2 * CO_BLK * 8;
     hipLaunchKernelGGL(conv_pack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout,
-                       n_chunks, total, full ? 1 : 0);
+                       n_chunks, total, full ? 1 : 0, fix);
     I2L_CHECK_LAUNCH();
     const int rows = 2 * Hp, cols = 2 * Wp;
     // tile shape with the fewest wasted positions (8x32, 16x16 or 4x64; ties: 8x32)
@@ -566,22 +664,23 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     do {                                                                                                              \
         if (full && Cout == 32)                                                                                       \
             hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, true, false, 1>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, \
-                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg, fix); \
         else if (full)                                                                                                \
             hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, true>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y,  \
-                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg, fix); \
         else if (amax)                                                                                                \
             hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, false, true>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, \
-                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg, fix); \
         else                                                                                                          \
             hipLaunchKernelGGL((conv3x3_bf16x3_kernel<WXV, false>), grid, dim3(256), 0, s, x, (const bf16_t*)wp, bias, y, \
-                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg); \
+                               amax, Cin, H, W, Cout, Hp, Wp, tiles_x, n_chunks, tiles_per_img, n_items, items_per_wg, fix); \
     } while (0)
     if (wx == 2) I2L_LAUNCH3(2);
     else if (wx == 1) I2L_LAUNCH3(1);
     else I2L_LAUNCH3(4);
 #undef I2L_LAUNCH3
     I2L_CHECK_LAUNCH();
+    if (amax) return launch_fixup(x, w, bias, y, amax, fix, B, Cin, H, W, Cout, s);
     return I2L_OK;
 }
 
@@ -590,12 +689,19 @@ bool i2l_conv_smallk_applicable(int Cin, int Cout) {
 }
 
 int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
-                        int H, int W, int Cout, hipStream_t s) {
+                        int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const int Hp = H / 2, Wp = W / 2;
+    unsigned* fix = nullptr;
+    if (amax) {                                                 // training forward: near-decision list at the workspace's start
+        if (!workspace || workspace_bytes < i2l_conv_fixlist_bytes()) return I2L_ERR_WORKSPACE;
+        if ((size_t)B * Cout * Hp * Wp > 0xffffffffull) return I2L_ERR_UNSUPPORTED;
+        fix = static_cast<unsigned*>(workspace);
+        if (hipMemsetAsync(fix, 0, sizeof(unsigned), s) != hipSuccess) return I2L_ERR_LAUNCH;
+    }
     const int tiles_x = i2l_cdiv(2 * Wp, 32), bands = i2l_cdiv(2 * Hp, 8);
     if (bands > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
     dim3 grid(Cout / 32, bands, B);
-#define I2L_LAUNCH_SK(C, A) hipLaunchKernelGGL((conv3x3_smallk_bf16x3_kernel<C, A>), grid, dim3(256), 0, s, x, w, bias, y, amax, H, W, Cout, Hp, Wp, tiles_x)
+#define I2L_LAUNCH_SK(C, A) hipLaunchKernelGGL((conv3x3_smallk_bf16x3_kernel<C, A>), grid, dim3(256), 0, s, x, w, bias, y, amax, H, W, Cout, Hp, Wp, tiles_x, fix)
     if (amax) {
         if (Cin == 1) I2L_LAUNCH_SK(1, true);
         else if (Cin == 2) I2L_LAUNCH_SK(2, true);
@@ -607,5 +713,6 @@ int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float
     }
 #undef I2L_LAUNCH_SK
     I2L_CHECK_LAUNCH();
+    if (amax) return launch_fixup(x, w, bias, y, amax, fix, B, Cin, H, W, Cout, s);
     return I2L_OK;
 }

@@ -21,7 +21,7 @@ SELECT_LOGITS, SELECT_SOFTMAX, SELECT_SAMPLE = 0, 1, 2
 PREP_WEIGHTS, PREP_ROWS, PREP_ALL = 1, 2, 3
 MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
 # kernel-selection flags (include/img2latex_hip.h I2L_FLAG_*): explicit arguments, the library reads no environment
-FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM, FLAG_TRAIN_FWD_SPLIT = 0x1, 0x2, 0x4, 0x8, 0x10
+FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0x1, 0x2, 0x4, 0x8
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
 
 

@@ -50,9 +50,6 @@ typedef void* i2l_stream_t;
                                           the grouped kernels (4 co-resident workgroups exchanging through L2)       */
 #define I2L_FLAG_RESNET_NO_RING 0x4    /* i2l_conv_bn_act_bf16_fwd: single-buffered GEMM instead of the LDS ring      */
 #define I2L_FLAG_RESNET_IM2COL_STEM 0x8 /* i2l_conv_bn_act_bf16_fwd: im2col image + GEMM instead of the fused stem    */
-#define I2L_FLAG_TRAIN_FWD_SPLIT 0x10  /* i2l_conv3x3_relu_pool2_fwd with argmax_out (training forward): 3 x bf16 split
-                                          kernels instead of the exact-fp32 ones (faster; conv gradients then keep the
-                                          float64 class of error but no longer follow ATen's rounding, see conv.hip)   */
 #define I2L_FLAG_AGENT_SCOPE_EXCHANGE 0x20 /* grouped kernels (greedy, beam, training recurrences): every exchange store at
                                           agent scope (sc1, write-through) -- the HSA-memory-model-conformant flavour --
                                           even when the group's members share an XCD and the faster L2-local
@@ -69,11 +66,13 @@ const char* i2l_error_string(int code);
 /* One CNN block: y = maxpool2x2(relu(conv3x3_pad1(x, w) + bias)), floor pooling.
  * Replaces nn.Conv2d + nn.ReLU + nn.MaxPool2d, encoder.py:78-95 executed at :122.
  * x (B,Cin,H,W)  w (Cout,Cin,3,3)  bias (Cout)  y (B,Cout,H/2,W/2), NCHW fp32.
- * Arithmetic: with argmax_out == NULL (inference), or I2L_FLAG_TRAIN_FWD_SPLIT, and Cin <= 3 or Cin % 16 == 0, Cout % 32/64 == 0 the products
+ * Arithmetic: with Cin <= 3 or Cin % 16 == 0, Cout % 32/64 == 0 the products
  * run on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces (six partial
  * products, fp32 accumulation): fp32-grade results (~2^-24 relative per product), not bit-identical to an fmaf
- * chain.  flags & I2L_FLAG_EXACT_FP32, a non-NULL argmax_out without I2L_FLAG_TRAIN_FWD_SPLIT, and other shapes use the
- * exact fp32 kernels.  The same applies to i2l_linear_bias_act_fwd for K >= 2048.
+ * chain.  flags & I2L_FLAG_EXACT_FP32 and other shapes use the exact fp32 kernels.  With argmax_out (training forward)
+ * the split kernels also list every pooling window whose arg max or ReLU gate is decided by less than 2^-13 of its
+ * magnitude, and a fix-up kernel re-evaluates those windows with fp32 FMAs, so the discrete decisions the backward
+ * pass branches on are an fp32 computation's.  The same split applies to i2l_linear_bias_act_fwd for K >= 2048.
  * Limits of the split arithmetic (tests/test_hip_parity.py::test_bf16x3_*): the error class is that of an fp32 fmaf
  * chain, |err| <= ~2^-22 (sum |x||w| + |b|), for operands of magnitude 0 or >= 2^-110 (below that the low split
  * pieces fall into bf16's subnormal range and the class degrades towards bf16); inputs must be finite -- a

@@ -37,19 +37,36 @@ def conv_block(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, pool: int = 2)
     return F.max_pool2d(F.relu(F.conv2d(x, w, b, padding=k // 2)), pool)
 
 
-def cnn_blocks(sd: SD, cfg: Dict, x: torch.Tensor) -> List[torch.Tensor]:
-    """Outputs of every conv block (Sequential idx 0,3,6 hold the convs, encoder.py:78-95)."""
+def pool_windows(conv: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) -> (B,C,H/2,W/2,4): the four values of every 2x2 pooling window, index 2*dy + dx (floor pooling)."""
+    B, C, H, W = conv.shape
+    c = conv[:, :, : H // 2 * 2, : W // 2 * 2]
+    return c.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
+
+
+def conv_block_decided(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, argmax: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """conv_block with the two DISCRETE choices of the block imposed instead of evaluated: `argmax` (which of the four
+    window values is pooled) and `gate` (whether the pooled value passes the ReLU).  The result is the same smooth
+    function of (x, w, b) that the block is wherever those choices are the block's own -- test tooling to separate an
+    implementation's rounding of the smooth part from its resolution of near-ties (tests/test_hip_training.py)."""
+    win = pool_windows(F.conv2d(x, w, b, padding=w.shape[-1] // 2))
+    return win.gather(-1, argmax.long().unsqueeze(-1)).squeeze(-1) * gate.to(win.dtype)
+
+
+def cnn_blocks(sd: SD, cfg: Dict, x: torch.Tensor, decisions=None) -> List[torch.Tensor]:
+    """Outputs of every conv block (Sequential idx 0,3,6 hold the convs, encoder.py:78-95).
+    decisions: None, or per block (argmax, gate) for conv_block_decided."""
     outs = []
     for i in range(len(cfg["conv_filters"])):
-        x = conv_block(x, sd[f"encoder.cnn_layers.{3 * i}.weight"],
-                       sd[f"encoder.cnn_layers.{3 * i}.bias"], cfg["pool_size"])
+        w, b = sd[f"encoder.cnn_layers.{3 * i}.weight"], sd[f"encoder.cnn_layers.{3 * i}.bias"]
+        x = conv_block(x, w, b, cfg["pool_size"]) if decisions is None else conv_block_decided(x, w, b, *decisions[i])
         outs.append(x)
     return outs
 
 
-def cnn_encoder(sd: SD, cfg: Dict, x: torch.Tensor) -> torch.Tensor:
+def cnn_encoder(sd: SD, cfg: Dict, x: torch.Tensor, decisions=None) -> torch.Tensor:
     """CNNEncoder.forward: blocks -> Flatten (NCHW row-major) -> Linear -> ReLU (encoder.py:111-129)."""
-    feat = cnn_blocks(sd, cfg, x)[-1].flatten(1)
+    feat = cnn_blocks(sd, cfg, x, decisions)[-1].flatten(1)
     return F.relu(F.linear(feat, sd["encoder.embedding_layer.weight"],
                            sd["encoder.embedding_layer.bias"]))
 
@@ -155,9 +172,9 @@ def decoder_forward(sd: SD, cfg: Dict, enc: torch.Tensor, target: torch.Tensor,
 # seq2seq  (reference img2latex/model/seq2seq.py)
 # --------------------------------------------------------------------------
 def seq2seq_forward(sd: SD, cfg: Dict, images: torch.Tensor, formulas: torch.Tensor,
-                    dropout_p: float = 0.0, training: bool = False) -> torch.Tensor:
+                    dropout_p: float = 0.0, training: bool = False, decisions=None) -> torch.Tensor:
     """Seq2SeqModel.forward: decoder(encoder(images), formulas[:, :-1]) (seq2seq.py:98-122)."""
-    return decoder_forward(sd, cfg, cnn_encoder(sd, cfg, images), formulas[:, :-1],
+    return decoder_forward(sd, cfg, cnn_encoder(sd, cfg, images, decisions), formulas[:, :-1],
                            dropout_p, training)
 
 
@@ -361,15 +378,17 @@ def adam_step(sd: SD, grads: Dict[str, torch.Tensor], state: Dict, lr: float = 1
 
 
 def loss_and_grads(sd: SD, cfg: Dict, images: torch.Tensor, formulas: torch.Tensor, pad_id: int = 0,
-                   dtype: torch.dtype = torch.float32):
+                   dtype: torch.dtype = torch.float32, decisions=None):
     """Loss and d(loss)/d(parameter) of the training forward (trainer.py:334-337), dropout off, evaluated in ``dtype``.
     float64 gives the reference point for judging fp32 results: the pooling arg max and the ReLU boundary make the
-    conv gradients discontinuous, so two correct fp32 evaluations differ by ~1e-3 of a gradient's maximum."""
+    conv gradients discontinuous, so two correct fp32 evaluations differ by ~1e-3 of a gradient's maximum.
+    ``decisions`` (per conv block (argmax, gate), see conv_block_decided) imposes an implementation's discrete choices,
+    which leaves a smooth function whose float64 gradient that implementation must match closely."""
     old = torch.get_default_dtype()
     torch.set_default_dtype(dtype)
     try:
         params = {k: v.detach().to(dtype).requires_grad_(True) for k, v in sd.items()}
-        logits = seq2seq_forward(params, cfg, images.to(dtype), formulas)
+        logits = seq2seq_forward(params, cfg, images.to(dtype), formulas, decisions=decisions)
         loss = ce_label_smooth(logits, formulas[:, 1:], pad_id)
         gl = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
     finally:

@@ -14,7 +14,7 @@ import torch
 
 import img2latex_oracle as O
 from conftest import record
-from helpers import PAD
+from helpers import PAD, adam_first_step_allowance, check_decisions, hip_decisions
 from img2latex_amd import _lib, synth
 from img2latex_amd.model import Seq2SeqModel
 
@@ -55,12 +55,18 @@ def test_cfg3_train_step_full_size_vs_oracle():
     assert loss_err <= 1e-5, loss_err
     assert logit_err <= 1e-4, logit_err                              # absolute (north_star: logits within 1e-4)
     # Gradients.  Norms against the fp32 oracle (3e-4).  Element by element the fp32 oracle is NOT the yardstick: the
-    # pooling arg max and the ReLU boundary make the conv gradients discontinuous in the rounding of the forward pass,
-    # so two correct fp32 evaluations differ by ~1e-3 of a gradient's maximum (measured: the oracle in fp32 vs the
-    # oracle in fp64).  Every element is therefore judged against the FLOAT64 oracle and must be no further from it
-    # than 3e-4 of the gradient's maximum, or 5x the fp32 oracle's own distance where that is larger (both recorded).
+    # pooling arg max and the ReLU gate make the conv gradients discontinuous in the rounding of the forward pass, so
+    # two correct fp32 evaluations differ by ~1e-3 of a gradient's maximum wherever one of the 18 M pooling windows is
+    # a near-tie (measured: the oracle in fp32 vs the oracle in fp64).  So the HIP forward's choices must differ from
+    # float64's only at near-ties fp32 cannot resolve (helpers.check_decisions), and every element is judged against
+    # the FLOAT64 gradient under those same choices, where only smooth rounding is left: 5e-5 of the gradient's maximum.
+    decisions = hip_decisions(m, x.to(DEV))
+    n_off, n_all = check_decisions(O.to_torch_sd(np_sd), cfg, x, decisions)
+    record(f"cfg3 B=64 HIP forward: windows deciding differently from float64 [of {n_all}]", n_off)
+    assert n_off <= 20 + n_all // 500000, (n_off, n_all)
     _, g64 = O.loss_and_grads(O.to_torch_sd(np_sd), cfg, x, forms, PAD, torch.float64)
-    worst_norm, worst_elem, worst_ratio = 0.0, 0.0, 0.0
+    _, g64d = O.loss_and_grads(O.to_torch_sd(np_sd), cfg, x, forms, PAD, torch.float64, decisions)
+    worst_norm, worst_elem, worst_ref = 0.0, 0.0, 0.0
     for name, _ in m.named_parameters():
         g = (ts.grad_views[name] / count).cpu().double()
         r = ref["grads"][name].double()
@@ -69,52 +75,55 @@ def test_cfg3_train_step_full_size_vs_oracle():
             assert float(g.abs().max()) == 0.0 and rn == 0.0         # exactly-zero gradients (length-1 source)
             continue
         ne = abs(float(g.norm()) - rn) / rn
-        t = g64[name]
-        scale = float(t.abs().max())
-        e_hip, e_ref = float((g - t).abs().max()) / scale, float((r - t).abs().max()) / scale
-        worst_norm, worst_elem = max(worst_norm, ne), max(worst_elem, e_hip)
-        worst_ratio = max(worst_ratio, e_hip / max(e_ref, 1e-4))
-        record(f"cfg3 B=64 T=149 d{name} vs fp64 oracle [rel to max]: HIP", e_hip)
-        record(f"cfg3 B=64 T=149 d{name} vs fp64 oracle [rel to max]: fp32 oracle", e_ref)
+        t = g64d[name]
+        e_hip = float((g - t).abs().max()) / float(t.abs().max())
+        e_ref = float((r - g64[name]).abs().max()) / float(g64[name].abs().max())
+        worst_norm, worst_elem, worst_ref = max(worst_norm, ne), max(worst_elem, e_hip), max(worst_ref, e_ref)
+        record(f"cfg3 B=64 T=149 d{name} vs fp64 oracle under the same decisions [rel to max]: HIP", e_hip)
+        record(f"cfg3 B=64 T=149 d{name}: fp32 oracle vs fp64 oracle, each with its own decisions [rel to max]", e_ref)
         assert ne <= 3e-4, (name, ne)
-        assert e_hip <= max(3e-4, 5.0 * e_ref), (name, e_hip, e_ref)
+        assert e_hip <= 5e-5, (name, e_hip)
     ts.apply()
     tn_err = abs(float(ts.stats[0]) - ref["total_norm"]) / ref["total_norm"]
     assert tn_err <= 3e-4, tn_err
     assert float(ts.stats[3]) == 0.0
     # parameters after the step.  Adam's first update is lr * g / (|g| + eps): an element whose |g| is at the level
     # of the gradient's own rounding error moves by up to lr either way, so (a) the clip + Adam kernel is checked
-    # EXACTLY by running the oracle's Adam on the HIP gradients (all 11.6 M elements, 3e-6), and (b) against the
+    # by running the oracle's Adam on the HIP gradients (all 11.6 M elements: 3e-6 plus what a 1e-4 uncertainty of the
+    # clip coefficient explains -- the total norm is accumulated in double here, in fp32 by torch), and (b) against the
     # oracle's own parameters each element gets 3e-6 plus what its gradient error explains through Adam's update rule
     hip_grads = {n: (ts.grad_views[n] / count).cpu() for n, _ in m.named_parameters()}
+    raw_hip = {n: g.clone() for n, g in hip_grads.items()}
     sd_a = O.to_torch_sd(np_sd)
-    O.clip_grad_norm(hip_grads, 5.0)
+    coef_hip = min(1.0, 5.0 / (float(O.clip_grad_norm(hip_grads, 5.0)) + 1e-6))
+    coef_ref = min(1.0, 5.0 / (ref["total_norm"] + 1e-6))
     with torch.no_grad():
         O.adam_step(sd_a, hip_grads, {}, 1e-3, 1e-4)
     worst_a, worst_b, n_plain, n_all = 0.0, 0.0, 0, 0
     for name, p in m.named_parameters():
         got = p.detach().cpu()
-        worst_a = max(worst_a, float((got - sd_a[name]).abs().max()))
+        worst_a = max(worst_a, float(((got - sd_a[name]).abs()
+                                      - adam_first_step_allowance(raw_hip[name], raw_hip[name], torch.from_numpy(np_sd[name]),
+                                                                  coef_hip, coef_hip, 1e-4)).max()))
         g_ref = ref["grads"][name]
         d = (got - sd[name]).abs()
         # first Adam step: p -= lr * f(g + wd * p0), f(x) = x / (|x| + eps); |f(a) - f(b)| <= min(2, |a - b| / (min(|a|, |b|) + eps))
         p0 = torch.from_numpy(np_sd[name])
-        ea, eb = g_ref + 1e-4 * p0, hip_grads[name] + 1e-4 * p0
-        allowed = 3e-6 + 1e-3 * torch.clamp((ea - eb).abs() / (torch.minimum(ea.abs(), eb.abs()) + 1e-8), max=2.0)
+        allowed = adam_first_step_allowance(g_ref, raw_hip[name], p0, coef_ref, coef_hip, 1e-4)
         worst_b = max(worst_b, float((d - allowed).max()))
         n_plain += int((d <= 3e-6).sum())
         n_all += d.numel()
-    assert worst_a <= 3e-6, worst_a
+    assert worst_a <= 0.0, worst_a
     assert worst_b <= 0.0, worst_b
     assert n_plain >= 0.9 * n_all, (n_plain, n_all)
     for k, v in (("loss [rel]", loss_err), ("logits [abs]", logit_err), ("grad norms [rel]", worst_norm),
-                 ("grads elementwise vs fp64 oracle [rel to max]", worst_elem), ("total norm [rel]", tn_err),
-                 ("clip+Adam kernel vs oracle Adam on the same gradients [abs]", worst_a)):
+                 ("grads elementwise vs fp64 oracle under the same decisions [rel to max]", worst_elem), ("total norm [rel]", tn_err),
+                 ("clip+Adam kernel vs oracle Adam on the same gradients [abs excess over 3e-6 + first-step allowance, <= 0]", worst_a)):
         record("cfg3 B=64 T=149 " + k, v)
     print(f"\n[cfg3 B=64 T=149] loss rel err {loss_err:.2e}, logits max abs err {logit_err:.2e}, grad-norm rel err "
-          f"{worst_norm:.2e}, grad elementwise err vs the fp64 oracle {worst_elem:.2e} of max ({worst_ratio:.1f}x the fp32 oracle's "
-          f"own), total-norm rel err {tn_err:.2e}, "
-          f"clip+Adam kernel vs oracle Adam on the same gradients {worst_a:.2e}, {n_plain}/{n_all} parameters within "
+          f"{worst_norm:.2e}, grad elementwise err vs the fp64 oracle under the same decisions {worst_elem:.2e} of max (fp32 "
+          f"oracle vs fp64 oracle, own decisions: {worst_ref:.2e}), total-norm rel err {tn_err:.2e}, "
+          f"clip+Adam kernel vs oracle Adam on the same gradients: excess over the allowance {worst_a:.2e}, {n_plain}/{n_all} parameters within "
           f"3e-6 of the oracle's step")
 
 

@@ -4,10 +4,12 @@ import json
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import img2latex_oracle as O
 from conftest import record
-from helpers import ALL, PAD, SMALL, images, load, sample, torch_state_dict
+from helpers import (ALL, PAD, SMALL, adam_first_step_allowance, check_decisions, hip_decisions, images, load, sample,
+                     torch_state_dict)
 from img2latex_amd import _lib, synth
 from img2latex_amd.model import Seq2SeqModel
 
@@ -100,47 +102,100 @@ def test_ce_kernel_vs_torch():
         rel_close(dl.cpu().numpy(), ref_logits.grad.numpy(), 1e-5, "dlogits")
 
 
-@pytest.mark.parametrize("variant", ["default", "exact", "split_forward"])
+@pytest.mark.parametrize("variant", ["default", "exact"])
 @pytest.mark.parametrize("name", SMALL + ["primary"])
 def test_encoder_backward_vs_oracle(name, variant):
-    """d(sum(enc * r))/d(encoder params) against the oracle's autograd, 3e-4 of each gradient's maximum (default kernels
-    and I2L_FLAG_EXACT_FP32).
-    The conv weight gradients are sums of ~10^5..10^6 products of both signs that cancel to ~1e-3 of their magnitude,
-    and they are non-smooth in the forward values (ReLU boundary, pooling arg max): two correct fp32 evaluations -- the
-    oracle in fp32 vs the oracle in fp64 -- already differ by up to 4e-3 of a gradient's maximum (recorded).  That is why
-    the training forward stays on the exact-fp32 kernels by default (they follow ATen's rounding, so the 3e-4 holds), and
-    why the opt-in I2L_FLAG_TRAIN_FWD_SPLIT forward (3 x bf16 split products, 0.11 ms per 64-image step faster) is
-    judged against the FLOAT64 oracle instead: 1e-2 of the maximum element-wise, 3e-4 on every gradient's norm."""
+    """d(sum(enc * r))/d(encoder params) against the oracle's autograd.
+    The conv gradients are sums of ~10^5..10^6 products of both signs that cancel to ~1e-3 of their magnitude, and they
+    are discontinuous in the forward pass's discrete choices (pooling arg max, ReLU gate): two correct fp32 evaluations
+    -- the oracle in fp32 vs the oracle in fp64 -- differ by up to 4e-3 of a gradient's maximum wherever one window is
+    a near-tie (recorded).  So: (1) the choices of the HIP forward may differ from float64's only at near-ties fp32
+    cannot resolve (helpers.check_decisions); (2) element by element the gradients are compared with the FLOAT64
+    gradient under those same choices -- smooth rounding only, 5e-5 of each gradient's maximum; (3) every gradient's
+    norm is within 3e-4 of the fp32 oracle's.  `default` runs the forward on the 3 x bf16 split kernels, whose near-tie
+    windows are re-evaluated with fp32 FMAs (conv_pool_fixup_kernel); `exact` is I2L_FLAG_EXACT_FP32."""
     d, cfg, m = build(name)
     sd = torch_state_dict(name)
     x = images(cfg)
     r = torch.from_numpy(synth.uniform(5, "probe", (4, cfg["embedding_dim"]), -1.0, 1.0))
 
-    def oracle(dtype):
+    def oracle(dtype, decisions=None):
         params = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
-        enc_ = O.cnn_encoder({**{k: v.to(dtype) for k, v in sd.items()}, **params}, cfg, x.to(dtype))
+        enc_ = O.cnn_encoder({**{k: v.to(dtype) for k, v in sd.items()}, **params}, cfg, x.to(dtype), decisions)
         (enc_ * r.to(dtype)).sum().backward()
         return enc_.detach(), {k: p.grad for k, p in params.items()}
     enc_cpu, g32 = oracle(torch.float32)
     _, g64 = oracle(torch.float64)
     m.train()
-    m.encoder.kernel_flags = {"default": 0, "exact": _lib.FLAG_EXACT_FP32, "split_forward": _lib.FLAG_TRAIN_FWD_SPLIT}[variant]
+    m.encoder.kernel_flags = {"default": 0, "exact": _lib.FLAG_EXACT_FP32}[variant]
+    decisions = hip_decisions(m, x.to(DEV))
+    n_off, n_all = check_decisions(sd, cfg, x, decisions)
+    record(f"{name} B=4 HIP {variant}: windows deciding differently from float64 [of {n_all}]", n_off)
+    _, g64d = oracle(torch.float64, decisions)
     enc = m.encoder(x.to(DEV))
     rel_close(enc.detach().cpu().numpy(), enc_cpu.numpy(), 1e-5, "enc")
     (enc * r.to(DEV)).sum().backward()
     for n, p in m.encoder.named_parameters():
-        t = g64["encoder." + n]
+        t = g64d["encoder." + n]
         scale = float(t.abs().max())
         g = p.grad.cpu().double()
         e_hip = float((g - t).abs().max()) / scale
-        e_ref = float((g32["encoder." + n].double() - t).abs().max()) / scale
-        record(f"{name} B=4 d{n} vs fp64 oracle [rel to max]: HIP {variant}", e_hip)
-        record(f"{name} B=4 d{n} vs fp64 oracle [rel to max]: fp32 oracle", e_ref)
-        if variant == "split_forward":
-            assert e_hip <= 1e-2, (n, e_hip, e_ref)
-            assert abs(float(g.norm()) - float(t.norm())) <= 3e-4 * float(t.norm()), n
-        else:
-            rel_close(p.grad.cpu().numpy(), g32["encoder." + n].numpy(), 3e-4, n)
+        e_ref = float((g32["encoder." + n].double() - g64["encoder." + n]).abs().max()) / float(g64["encoder." + n].abs().max())
+        record(f"{name} B=4 d{n} vs fp64 oracle under the same decisions [rel to max]: HIP {variant}", e_hip)
+        record(f"{name} B=4 d{n}: fp32 oracle vs fp64 oracle, each with its own decisions [rel to max]", e_ref)
+        assert e_hip <= 5e-5, (n, e_hip)
+        n32 = float(g32["encoder." + n].norm())
+        assert abs(float(g.norm()) - n32) <= 3e-4 * n32, n
+
+
+def test_training_forward_decisions_match_fp32():
+    """The pooling arg max and the ReLU gate of the split-product training forward against a float64 evaluation, on
+    the three block shapes of the primary config at 16 images: every window where the two disagree must be a genuine
+    fp32 near-tie (top-two gap / pre-activation below 2e-6 of the window's magnitude -- where fp32 evaluations disagree
+    among themselves), and the exact-fp32 kernels must not do better by more than a handful of windows.  Data with
+    exact ties (constant regions) must give the first index in both."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+
+    def run(x, w, b, flags):
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        y = torch.empty(B, Cout, H // 2, W // 2, device=DEV)
+        am = torch.empty(B, Cout, H // 2, W // 2, dtype=torch.uint8, device=DEV)
+        nbytes = L.i2l_conv_workspace_bytes(Cin, Cout)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
+        assert L.i2l_conv3x3_relu_pool2_fwd(x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), y.data_ptr(),
+                                            am.data_ptr(), B, Cin, H, W, Cout, ws.data_ptr(), nbytes, flags,
+                                            _lib.stream_ptr()) == 0
+        return y.cpu(), am.cpu()
+
+    for (Cin, Cout, H, W) in [(3, 32, 64, 320), (32, 64, 32, 160), (64, 128, 16, 80)]:
+        x = torch.rand(16, Cin, H, W, generator=g) * 2 - 1
+        if Cin == 3:
+            x[:, :, :, 200:] = 1.0                                     # white margin: exact ties
+        w = (torch.rand(Cout, Cin, 3, 3, generator=g) * 2 - 1) / (Cin * 9) ** 0.5
+        b = (torch.rand(Cout, generator=g) * 2 - 1) * 0.1
+        conv = F.conv2d(x.double(), w.double(), None, padding=1)       # float64 pre-bias
+        B_, C_, Hc, Wc = conv.shape
+        quads = conv.reshape(B_, C_, Hc // 2, 2, Wc // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B_, C_, Hc // 2, Wc // 2, 4)
+        top2 = quads.topk(2, dim=-1).values
+        ref_am = quads.argmax(dim=-1)                                  # first maximum
+        gap = top2[..., 0] - top2[..., 1]
+        pre = top2[..., 0] + b.double()[None, :, None, None]
+        mag = quads.abs().amax(dim=-1).clamp_min(1e-30)
+        counts = {}
+        for flags in (0, _lib.FLAG_EXACT_FP32):
+            y, am = run(x, w, b, flags)
+            live = pre > 0                                             # the arg max only matters where the ReLU passes
+            wrong_am = (am.long() != ref_am) & live & (gap > 0)
+            wrong_gate = (y > 0) != (pre > 0)
+            assert float((gap[wrong_am] / mag[wrong_am]).max() if wrong_am.any() else 0.0) <= 2e-6, (Cin, flags)
+            assert float((pre[wrong_gate].abs() / mag[wrong_gate]).max() if wrong_gate.any() else 0.0) <= 2e-6, (Cin, flags)
+            tie = (gap == 0) & live
+            assert bool((am.long()[tie] == ref_am[tie]).all()), "exact ties take the first index"
+            counts[flags] = int(wrong_am.sum()) + int(wrong_gate.sum())
+            record(f"training forward decisions Cin={Cin} flags={flags} [windows off fp64 of {ref_am.numel()}]", counts[flags])
+        assert counts[0] <= counts[_lib.FLAG_EXACT_FP32] + 8 + ref_am.numel() // 500000, counts
 
 
 def test_conv_bwd_odd_shapes():
@@ -174,6 +229,46 @@ def test_conv_bwd_odd_shapes():
         rel_close(db.cpu().numpy(), b.grad.numpy(), 2e-4, "db")
 
 
+def _params_after_vs_fixture(name, cfg, names, sdict, after, d, x_cpu, forms_cpu, hip_grads):
+    """Parameters after the first clip + Adam step.  Adam's first update is lr * x / (|x| + eps) with x = coef * g +
+    wd * p0: an element whose |x| ~ eps = 1e-8 -- a tiny gradient, or a clipped gradient that happens to cancel the
+    weight-decay term (0.01 % of the elements here) -- moves by up to lr when x changes in its 7th digit, e.g. because
+    the total norm behind the clip coefficient is accumulated in double (HIP) instead of fp32 (torch: 6e-5 apart on
+    this model), or because one pooling near-tie was resolved the other way.  helpers.adam_first_step_allowance bounds
+    exactly that and nothing else, so:
+    (a) the optimizer arithmetic: the oracle's clip + Adam on the HIP gradients vs the HIP parameters, EVERY element,
+        3e-6 + the allowance for a 1e-4 uncertainty of the clip coefficient; 99.9 % of the elements within the plain 3e-6;
+    (b) fixture G6 (the REAL reference's step), sampled elements: 3e-6 + the allowance for the difference between the
+        HIP gradient and the fp32 oracle's gradient; 95 % of the sample within the plain 3e-6."""
+    sd0 = torch_state_dict(name)
+    ref = O.train_step({k: v.clone() for k, v in sd0.items()}, cfg, x_cpu, forms_cpu, {})
+    coef_ref = min(1.0, 5.0 / (ref["total_norm"] + 1e-6))
+    sd_a = {k: v.clone() for k, v in sd0.items()}
+    clipped = {n: g.clone() for n, g in hip_grads.items()}
+    coef_hip = min(1.0, 5.0 / (float(O.clip_grad_norm(clipped, 5.0)) + 1e-6))
+    with torch.no_grad():
+        O.adam_step(sd_a, clipped, {}, 1e-3, 1e-4)
+    worst, n_plain, n_all = 0.0, 0, 0
+    for n in names:
+        diff = (sdict[n].detach().cpu() - sd_a[n]).abs()
+        allowed = adam_first_step_allowance(hip_grads[n], hip_grads[n], sd0[n], coef_hip, coef_hip, 1e-4)
+        worst = max(worst, float((diff - allowed).max()))
+        n_plain += int((diff <= 3e-6).sum())
+        n_all += diff.numel()
+    record(f"{name} clip + Adam kernel vs the oracle's Adam on the same gradients [fraction within 3e-6]", n_plain / n_all)
+    assert worst <= 0.0, worst
+    assert n_plain >= 0.999 * n_all, (n_plain, n_all)
+
+    def smp(t):
+        return torch.from_numpy(sample(t, 8)[:8] if t.numel() >= 8 else np.resize(t.detach().cpu().numpy().ravel(), 8))
+    allowed = torch.stack([adam_first_step_allowance(smp(ref["grads"][n]), smp(hip_grads[n]), smp(sd0[n]), coef_ref, coef_hip, 1e-4)
+                           for n in names])
+    diff = torch.from_numpy(np.abs(after - d["g6_param_sample_after"]))
+    record(f"{name} parameters after one step vs fixture G6 [abs, worst of the sample]", float(diff.max()))
+    assert float((diff - allowed).max()) <= 0.0, float((diff - allowed).max())
+    assert int((diff <= 3e-6).sum()) >= 0.95 * diff.numel(), int((diff <= 3e-6).sum())
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_train_step_vs_reference_golden(name):
     """trainer.py:303-343 for one batch against fixture G6 produced by the REAL reference:
@@ -205,7 +300,8 @@ def test_train_step_vs_reference_golden(name):
     sdict = dict(m.named_parameters())
     after = np.stack([sample(sdict[k], 8)[:8] if sdict[k].numel() >= 8 else np.resize(sdict[k].detach().cpu().numpy().ravel(), 8)
                       for k in names])
-    np.testing.assert_allclose(after, d["g6_param_sample_after"], rtol=0, atol=3e-6)
+    _params_after_vs_fixture(name, cfg, names, sdict, after, d, x.cpu(), forms.cpu(),
+                             {n: (ts.grad_views[n] / count).cpu() for n in names})
     # the parameters are views into the flat buffer and the state_dict keys are untouched
     assert list(m.state_dict().keys()) == names
 
@@ -291,6 +387,7 @@ def test_reference_trainer_loop_over_the_dropin_model(name, amp):
         loss.backward()
     sdict = dict(m.named_parameters())
     gn = np.array([float(sdict[n].grad.cpu().norm()) for n in names])
+    raw_grads = {n: sdict[n].grad.detach().cpu().clone() for n in names}
     total = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)                                   # :338-341 / :323
     if amp:
         scaler.step(optimizer)
@@ -302,7 +399,8 @@ def test_reference_trainer_loop_over_the_dropin_model(name, amp):
     assert abs(float(total) - float(d["g6_total_norm"])) <= 3e-4 * float(d["g6_total_norm"])
     after = np.stack([sample(sdict[k], 8)[:8] if sdict[k].numel() >= 8 else np.resize(sdict[k].detach().cpu().numpy().ravel(), 8)
                       for k in names])
-    np.testing.assert_allclose(after, d["g6_param_sample_after"], rtol=0, atol=3e-6)
+    _params_after_vs_fixture(name, cfg, names, sdict, after, d, images_.cpu(), formulas.cpu(),
+                             raw_grads)
     optimizer.zero_grad(set_to_none=True)
     # the step changed the parameters through torch: the decoder's cached weight images must notice (p._version)
     m.eval()
