@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 template <int CIN, bool AM = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    unsigned char* __restrict__ amax, int H, int W, int Cout, int Hp, int Wp, int tiles_x, unsigned* __restrict__ fix) {
+    unsigned char* __restrict__ amax, int H, int W, int Cout, int Hp, int Wp, int tiles_x, int tiles_per_part,
+    unsigned* __restrict__ fix) {
     constexpr int RS = 48;                                   // pixels per patch row: rows r, r+1 half a bank row apart
     constexpr int PLANE = 10 * RS;                           // pixels per split plane
     __shared__ __attribute__((aligned(16))) uint2 img[3 * PLANE];
@@ -405,7 +406,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int i = lane & 31, h = lane >> 5;
-    const int cb = blockIdx.x, b = blockIdx.z;
+    // blockIdx.x = (part of the band's column tiles, 32-channel block): small batches split the walk so that the grid
+    // still fills the chip
+    const int cbs = (Cout + 31) / 32;
+    const int cb = blockIdx.x % cbs, b = blockIdx.z;
+    const int tx_begin = (blockIdx.x / cbs) * tiles_per_part, tx_end = min(tiles_x, tx_begin + tiles_per_part);
     const int y0 = blockIdx.y * 8;
 
     // B operand: k-step s, lane half h -> taps 4s + 2h, 4s + 2h + 1, channels 0..3 each
@@ -470,8 +475,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
             for (int c = 0; c < CIN; ++c) pin[e][c] = ok ? xb[c * HW + q_goff[e] + x0] : 0.f;
         }
     };
-    fetch(0);
-    for (int tx = 0; tx < tiles_x; ++tx) {
+    fetch(tx_begin);
+    for (int tx = tx_begin; tx < tx_end; ++tx) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (q_lds[e] >= 0) {
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
             }
         }
         __syncthreads();                                    // patch complete; out_s of the last tile consumed
-        if (tx + 1 < tiles_x) fetch(tx + 1);
+        if (tx + 1 < tx_end) fetch(tx + 1);
         f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -657,6 +662,9 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     if (n_items_ll > 0x7fffffffll) return I2L_ERR_UNSUPPORTED;
     const int n_items = (int)n_items_ll;
     int items_per_wg = (int)((n_items_ll * co_blocks + 511) / 512);
+    // a launch with little more than one resident round of single tiles (block 3 of a 64-image training batch: 640):
+    // one tile per workgroup fills the CUs more evenly than 320 walks of two (86 -> 73 us); measured worse above that
+    if (n_items_ll * co_blocks <= 768) items_per_wg = 1;
     if (items_per_wg < 1) items_per_wg = 1;
     const int walks = i2l_cdiv(n_items, items_per_wg);
     dim3 grid((unsigned)(i2l_cdiv(walks, 8) * 8 * co_blocks));       // ids decoded in the kernel (XCD-aware)
@@ -700,8 +708,13 @@ int i2l_conv_smallk_run(const float* x, const float* w, const float* bias, float
     }
     const int tiles_x = i2l_cdiv(2 * Wp, 32), bands = i2l_cdiv(2 * Hp, 8);
     if (bands > 65535 || B > 65535) return I2L_ERR_UNSUPPORTED;
-    dim3 grid(Cout / 32, bands, B);
-#define I2L_LAUNCH_SK(C, A) hipLaunchKernelGGL((conv3x3_smallk_bf16x3_kernel<C, A>), grid, dim3(256), 0, s, x, w, bias, y, amax, H, W, Cout, Hp, Wp, tiles_x, fix)
+    // at least ~6 workgroups per CU (3 resident): split each band's tile walk into parts when the batch is small
+    int parts = 1;
+    while (parts < tiles_x && (long)(Cout / 32) * bands * B * parts < 1536) ++parts;
+    const int tiles_per_part = i2l_cdiv(tiles_x, parts);
+    parts = i2l_cdiv(tiles_x, tiles_per_part);
+    dim3 grid((Cout / 32) * parts, bands, B);
+#define I2L_LAUNCH_SK(C, A) hipLaunchKernelGGL((conv3x3_smallk_bf16x3_kernel<C, A>), grid, dim3(256), 0, s, x, w, bias, y, amax, H, W, Cout, Hp, Wp, tiles_x, tiles_per_part, fix)
     if (amax) {
         if (Cin == 1) I2L_LAUNCH_SK(1, true);
         else if (Cin == 2) I2L_LAUNCH_SK(2, true);
