@@ -276,7 +276,9 @@ __device__ __forceinline__ void lsplit_piece(const float4& lo, const float4& hi,
     for (int sp = 0; sp < 3; ++sp) out[sp] = make_uint4(p[sp][0], p[sp][1], p[sp][2], p[sp][3]);
 }
 
-template <bool A_KC, bool W_KC, int MT>      // MT = 32-row MFMA tiles per wave: workgroup tile (64 MT) x 64
+// MT = 32-row MFMA tiles per wave: workgroup tile (64 MT) x 64.  PLAIN: one operand pair, no gathered / un-pooled
+// operand (the decoder's and the FC layer's GEMMs): the fetch is two 16-byte loads per piece, no index arithmetic
+template <bool A_KC, bool W_KC, int MT, bool PLAIN>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(GemmArgs g, float* __restrict__ partial, int k_chunk,
                                                              int S, int tiles_n, int tiles) {
     constexpr int LBM_ = 64 * MT, LPA_ = LBM_ + 2;
@@ -329,6 +331,13 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(GemmArgs g, float* 
         }
     };
     auto fetch = [&](Stage& st, long kf0) {
+        if constexpr (PLAIN) {
+            const int k0 = (int)kf0, kend = (int)kf_end;
+            load8(A_KC, pa0, g.lda, oka0, k0 + a_kg0 * 8, kend, st.a[0][0], st.a[0][1]);
+            if (MT == 2) load8(A_KC, pa1, g.lda, oka1, k0 + a_kg1 * 8, kend, st.a[1][0], st.a[1][1]);
+            load8(W_KC, pw, g.ldw, okw, k0 + w_kg * 8, kend, st.w[0], st.w[1]);
+            return;
+        }
         const int z = (int)(kf0 / g.K), k0 = (int)(kf0 - (long)z * g.K);
         const int kend = (int)min((long)g.K, kf_end - (long)z * g.K);
         const size_t oa = (size_t)z * g.bsa, ow = (size_t)z * g.bsw;
@@ -513,10 +522,13 @@ int run_bf16x3(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t s) {
     if (blocks > 0x7fffffffll) return I2L_ERR_UNSUPPORTED;
     dim3 grid((unsigned)blocks);
     float* wsf = static_cast<float*>(ws);
+    const bool plain = g.nz == 1 && !g.pool_y && g.conv_h <= 0;
 #define I2L_LAUNCH_BF16X3(AK, WK)                                                                                          \
     do {                                                                                                                \
-        if (mt == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 2>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles); \
-        else hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 1>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);  \
+        if (mt == 2 && plain) hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 2, true>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles); \
+        else if (mt == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 2, false>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles); \
+        else if (plain) hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 1, true>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles); \
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, WK, 1, false>), grid, dim3(256), 0, s, g, wsf, kc, S, tiles_n, tiles);  \
     } while (0)
     if (g.a_kc && g.w_kc) I2L_LAUNCH_BF16X3(true, true);
     else if (g.a_kc) I2L_LAUNCH_BF16X3(true, false);
