@@ -22,7 +22,7 @@
 //   F  per slot: local (max, sum exp) and top K -> published with tag step + 1
 // All four members hold the same per-image state and take the same decisions from the same data; member (image & 3)
 // writes the history and the result.  Exchange, placement check, progress argument and timeouts: decode_group.inc.h.
-// A timed-out poll ends the group with len_out = -3 (i2l_beam_decode then has to be re-run with I2L_BEAM_GROUP=0).
+// A timed-out poll ends the group with len_out = -3 (i2l_beam_decode is then re-run with I2L_FLAG_NO_GROUP).
 
 constexpr int BG_NP = 3;                         // passes of 4 row slots
 constexpr int BG_S = 4 * BG_NP;                  // row slots per group

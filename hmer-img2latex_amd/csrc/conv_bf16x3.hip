@@ -389,8 +389,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 // read by two ds_read_b64 -- no im2col image, no per-tap splitting.  K = 9 taps x 4 = 36 -> 3 k-steps of 16 (taps
 // 9..11 carry zero weights); the filter bank (32 output channels x 48 k x 3 splits) sits in 36 registers per lane
 // for the whole kernel.  A workgroup walks the column tiles of an 8-row band (8 x 32 positions per tile, 2 M-tiles
-// per wave, 18 MFMAs per M-tile) with the next patch prefetched in registers; ~20 KB of LDS and <= 128 registers
-// let four workgroups share a CU, so one's staging / epilogue hides behind the others' MFMAs.
+// per wave, 18 MFMAs per M-tile) with the next patch prefetched in registers; ~20 KB of LDS and ~165 registers
+// let three workgroups share a CU, so one's staging / epilogue hides behind the others' MFMAs (four would need
+// <= 128 registers: 45-99 spills, measured slower).  The pooled tile goes through LDS so that every store
+// instruction writes 64-byte runs; storing 16 bytes per lane straight from the accumulators (v_permlane32_swap to
+// gather a lane's four columns) saves the transpose and a barrier but halves the run length: 0.106 -> 0.122 ms.
 // ---------------------------------------------------------------------------------------------------------------
 template <int CIN, bool AM = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
