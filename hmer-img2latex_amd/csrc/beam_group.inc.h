@@ -425,9 +425,9 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
                 const float cp = cs[ps * 64 + ul];
                 const float xi = (zz.x + ge[pp].x) + pv[pp].x, xf = (zz.y + ge[pp].y) + pv[pp].y;
                 const float xc = (zz.z + ge[pp].z) + pv[pp].z, xo = (zz.w + ge[pp].w) + pv[pp].w;
-                const float ig = sigmoidf_(xi), fg = sigmoidf_(xf), gg = tanhf(xc), og = sigmoidf_(xo);
+                const float ig = sigmoidf_(xi), fg = sigmoidf_(xf), gg = tanhf_(xc), og = sigmoidf_(xo);
                 c_new[pp] = fg * cp + ig * gg;
-                const float hn = og * tanhf(c_new[pp]);
+                const float hn = og * tanhf_(c_new[pp]);
                 store_granule(xslot + (size_t)m * BG_GRAN + q * 64 + ul, granule(epoch, hn), local);
                 h_s[pp * 1024 + (64 * m + ul) * 4 + ke] = hn;   // h_s was last read in A, before the barriers of B
             }

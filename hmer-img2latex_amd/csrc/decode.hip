@@ -123,7 +123,12 @@ struct DecodeParams {
     int top_k; float top_p; unsigned long long seed; float* probs;   // I2L_SELECT_SAMPLE only
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate functions of the search kernels (greedy, beam, row-per-workgroup): hardware exp2 / reciprocal (v_exp_f32,
+// v_rcp_f32: ~1 ulp each) instead of libm's expf / tanhf and an IEEE division -- the LSTM cell is a chain of five of
+// them on the critical path of every step (~150 dependent instructions -> ~30).  Absolute error <= ~2e-7 per call, the
+// class of the vectorised expf / tanhf ATen itself uses; saturation: exp -> inf gives 1/inf = 0, exp -> 0 gives -1 / 0+.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 // acc[r] += sum_k W[k][0..3] * x[r][k], k ascending (one fmaf chain per output).
 // The weight stream is software-pipelined: while the FMAs of one batch of PF rows run, the
@@ -276,10 +281,10 @@ __device__ __forceinline__ void lstm_layers(const StepWeights& w, const int (&to
             for (int r = 0; r < R; ++r) {
                 const size_t ci = ((size_t)l * R + r) * H + j;
                 const float ig = sigmoidf_(acc[r].x), fg = sigmoidf_(acc[r].y);
-                const float gg = tanhf(acc[r].z), og = sigmoidf_(acc[r].w);
+                const float gg = tanhf_(acc[r].z), og = sigmoidf_(acc[r].w);
                 const float cn = fg * c_in[ci] + ig * gg;
                 c_out[ci] = cn;
-                h_new[r * H + j] = og * tanhf(cn);
+                h_new[r * H + j] = og * tanhf_(cn);
             }
         }
         __syncthreads();
@@ -511,10 +516,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeParams p) {
                 for (int r = 0; r < R; ++r) {
                     acc[r].x += a[r].x; acc[r].y += a[r].y; acc[r].z += a[r].z; acc[r].w += a[r].w;
                     const float ig = sigmoidf_(acc[r].x), fg = sigmoidf_(acc[r].y);
-                    const float gg = tanhf(acc[r].z), og = sigmoidf_(acc[r].w);
+                    const float gg = tanhf_(acc[r].z), og = sigmoidf_(acc[r].w);
                     const float cn = fg * cs[r * H + tid] + ig * gg;
                     cs[r * H + tid] = cn;
-                    h_new[r * H + tid] = og * tanhf(cn);
+                    h_new[r * H + tid] = og * tanhf_(cn);
                 }
             }
             __syncthreads();

@@ -279,9 +279,9 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
             const float g2 = dpp_f<DPP_SHL4>(z[0]), g3 = dpp_f<DPP_SHL4>(z[1]);      // (g, o) from lane ke + 4
             const float xi = (z[0] + genc.x) + pvec.x, xf = (z[1] + genc.y) + pvec.y;
             const float xc = (g2 + genc.z) + pvec.z, xo = (g3 + genc.w) + pvec.w;
-            const float ig = sigmoidf_(xi), fg = sigmoidf_(xf), gg = tanhf(xc), og = sigmoidf_(xo);
+            const float ig = sigmoidf_(xi), fg = sigmoidf_(xf), gg = tanhf_(xc), og = sigmoidf_(xo);
             c_own = fg * c_own + ig * gg;
-            h_own = og * tanhf(c_own);
+            h_own = og * tanhf_(c_own);
         }
         if (ke < 4) {
             store_granule(slot + (size_t)m * GRAN + ul * 4 + ke, granule(epoch, h_own), local);

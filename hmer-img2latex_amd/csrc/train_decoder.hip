@@ -158,7 +158,9 @@ __device__ __forceinline__ void matvec_res(float4& acc, const float4 (&wres)[KR 
     acc = a1[0];
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// gate functions on the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32), as in decode.hip: <= ~2e-7 absolute per call
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 #include "train_group.inc.h"
 
@@ -213,9 +215,9 @@ __global__ __launch_bounds__(NT) void lstm_train_fwd_kernel(TrainBuf p) {
             float4 acc = *reinterpret_cast<const float4*>(p.GX + bt * G + 4 * tid);
             matvec_res<KR, KL>(acc, wres, wl + 4 * tid, (int)G, p.WhhT[0] + 4 * tid, G, h_old, H);
             const float ig = sigmoidf_(acc.x), fg = sigmoidf_(acc.y);
-            const float gg = tanhf(acc.z), og = sigmoidf_(acc.w);
+            const float gg = tanhf_(acc.z), og = sigmoidf_(acc.w);
             const float cn = fg * cs[tid] + ig * gg;
-            const float hn = og * tanhf(cn);
+            const float hn = og * tanhf_(cn);
             cs[tid] = cn;
             h_new[tid] = hn;
             *reinterpret_cast<float4*>(p.ACT[0] + bt * G + 4 * tid) = make_float4(ig, fg, gg, og);
@@ -249,9 +251,9 @@ __global__ __launch_bounds__(NT) void lstm_train_fwd_kernel(TrainBuf p) {
                 for (int r = 0; r < R; ++r) {
                     const size_t ci = ((size_t)l * R + r) * H + j;
                     const float ig = sigmoidf_(acc[r].x), fg = sigmoidf_(acc[r].y);
-                    const float gg = tanhf(acc[r].z), og = sigmoidf_(acc[r].w);
+                    const float gg = tanhf_(acc[r].z), og = sigmoidf_(acc[r].w);
                     const float cn = fg * cs[ci] + ig * gg;
-                    const float hn = og * tanhf(cn);
+                    const float hn = og * tanhf_(cn);
                     cs[ci] = cn;
                     h_new[r * H + j] = hn;
                     const int row = row0 + r;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(NT) void lstm_train_bwd_kernel(BwdBuf p) {
                     float dh = dh_rec[si];
                     if (l == L - 1) dh += p.dHtop[bt * H + j];
                     else dh += dh_low[r * H + j] * keep_scale(p.seed, DS_LAYER0 + l, bt * H + j, p.p, inv_keep);
-                    const float tc = tanhf(c);
+                    const float tc = tanhf_(c);
                     const float d_o = dh * tc * a.w * (1.f - a.w);
                     const float dc = dh * a.w * (1.f - tc * tc) + dc_next[si];
                     const float d_i = dc * a.z * a.x * (1.f - a.x);

@@ -131,10 +131,10 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group_kernel(TrainGroupFwd
             }
             const float g2 = dpp_f<DPP_SHL4>(z[0]), g3 = dpp_f<DPP_SHL4>(z[1]);
             const float ig = sigmoidf_(gx.x + z[0]), fg = sigmoidf_(gx.y + z[1]);
-            const float gg = tanhf(gx.z + g2), og = sigmoidf_(gx.w + g3);
+            const float gg = tanhf_(gx.z + g2), og = sigmoidf_(gx.w + g3);
             const float h_prev = h_own;
             c_own = fg * c_own + ig * gg;
-            h_own = og * tanhf(c_own);
+            h_own = og * tanhf_(c_own);
             if (live) {
                 *reinterpret_cast<float4*>(p.ACT + bt * G + 4 * unit) = make_float4(ig, fg, gg, og);
                 p.C[bt * H + unit] = c_own;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group_kernel(TrainGroupBwd
         prefetch(t - 1);
         if (owner) {
             const float dh = dh_rec + dht;
-            const float tc = tanhf(c);
+            const float tc = tanhf_(c);
             const float d_o = dh * tc * a.w * (1.f - a.w);
             const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
             const float d_i = dc * a.z * a.x * (1.f - a.x);
@@ -409,10 +409,10 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group2_kernel(TrainGroupFw
             const float zi = rs_level<DPP_XOR2>(wv[0], wv[1], b1);
             const float zf = dpp_f<DPP_SHL2>(zi), zg = dpp_f<DPP_SHL4>(zi), zo = dpp_f<DPP_SHL6>(zi);
             const float ig = sigmoidf_(gx.x + zi), fg = sigmoidf_(gx.y + zf);
-            const float gg = tanhf(gx.z + zg), og = sigmoidf_(gx.w + zo);
+            const float gg = tanhf_(gx.z + zg), og = sigmoidf_(gx.w + zo);
             const float h_prev = h_own;
             c_own = fg * c_own + ig * gg;
-            h_own = og * tanhf(c_own);
+            h_own = og * tanhf_(c_own);
             if (live) {
                 *reinterpret_cast<float4*>(p.ACT + bt * G + 4 * unit) = make_float4(ig, fg, gg, og);
                 p.C[bt * H + unit] = c_own;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group2_kernel(TrainGroupBw
         prefetch(t - 1);
         if (owner) {
             const float dh = dh_rec + dht;
-            const float tc = tanhf(c);
+            const float tc = tanhf_(c);
             const float d_o = dh * tc * a.w * (1.f - a.w);
             const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
             const float d_i = dc * a.z * a.x * (1.f - a.x);
@@ -676,10 +676,10 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group1_kernel(TrainGroupFw
             const float zi = wv + dpp_f<DPP_XOR2>(wv);
             const float zf = dpp_f<DPP_SHL1>(zi), zg = dpp_f<DPP_SHL4>(zi), zo = dpp_f<DPP_SHL5>(zi);
             const float ig = sigmoidf_(gx.x + zi), fg = sigmoidf_(gx.y + zf);
-            const float gg = tanhf(gx.z + zg), og = sigmoidf_(gx.w + zo);
+            const float gg = tanhf_(gx.z + zg), og = sigmoidf_(gx.w + zo);
             const float h_prev = h_own;
             c_own = fg * c_own + ig * gg;
-            h_own = og * tanhf(c_own);
+            h_own = og * tanhf_(c_own);
             if (live) {
                 *reinterpret_cast<float4*>(p.ACT + bt * G + 4 * unit) = make_float4(ig, fg, gg, og);
                 p.C[bt * H + unit] = c_own;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group1_kernel(TrainGroupBw
         prefetch(t - 1);
         if (owner) {
             const float dh = dh_rec + dht;
-            const float tc = tanhf(c);
+            const float tc = tanhf_(c);
             const float d_o = dh * tc * a.w * (1.f - a.w);
             const float dc = dh * a.w * (1.f - tc * tc) + dc_next;
             const float d_i = dc * a.z * a.x * (1.f - a.x);
