@@ -32,6 +32,8 @@ LAYERS = [
 def main():
     B = int(os.environ.get("B", "256"))
     FLAGS = int(os.environ.get("FLAGS", "0"))      # script-level switch, passed to the ABI as an explicit argument
+    if os.environ.get("LIB"):                    # A/B another build of the library on the same box
+        _lib.LIB_PATH = os.environ["LIB"]
     L = _lib.lib()
     dev = torch.device("cuda:0")
     total = 0.0
