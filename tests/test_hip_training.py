@@ -164,7 +164,8 @@ def test_training_forward_decisions_match_fp32():
         am = torch.empty(B, Cout, H // 2, W // 2, dtype=torch.uint8, device=DEV)
         nbytes = L.i2l_conv_workspace_bytes(Cin, Cout)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
-        assert L.i2l_conv3x3_relu_pool2_fwd(x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), y.data_ptr(),
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)                   # named: the device copies must outlive the launch
+        assert L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(),
                                             am.data_ptr(), B, Cin, H, W, Cout, ws.data_ptr(), nbytes, flags,
                                             _lib.stream_ptr()) == 0
         return y.cpu(), am.cpu()
@@ -196,6 +197,35 @@ def test_training_forward_decisions_match_fp32():
             counts[flags] = int(wrong_am.sum()) + int(wrong_gate.sum())
             record(f"training forward decisions Cin={Cin} flags={flags} [windows off fp64 of {ref_am.numel()}]", counts[flags])
         assert counts[0] <= counts[_lib.FLAG_EXACT_FP32] + 8 + ref_am.numel() // 500000, counts
+
+
+def test_training_forward_near_tie_list_overflow():
+    """An input made of near-ties (a constant image plus 1e-6 noise: almost every pooling window's runner-up is within
+    2^-13 of its maximum) overflows the fix-up list (1 M entries; 1.3 M windows here).  Nothing may break: the call
+    succeeds, the pooled values are the fp32-grade maxima, and every arg max points at a value within 1e-5 of its
+    window's maximum -- listed windows are re-evaluated in fp32, the overflow keeps the split-product decision."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, W, Cout = 8, 3, 64, 320, 32
+    x = 0.5 + 1e-6 * torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.rand(Cout, Cin, 3, 3, generator=g) * 2 - 1) / 27 ** 0.5
+    b = torch.rand(Cout, generator=g) * 0.1 + 0.5                      # keeps the ReLU open on all but one channel
+    y = torch.empty(B, Cout, H // 2, W // 2, device=DEV)
+    am = torch.empty(B, Cout, H // 2, W // 2, dtype=torch.uint8, device=DEV)
+    nbytes = L.i2l_conv_workspace_bytes(Cin, Cout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)                       # named: the device copies must outlive the launch
+    assert L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(),
+                                        am.data_ptr(), B, Cin, H, W, Cout, ws.data_ptr(), nbytes, 0, _lib.stream_ptr()) == 0
+    listed = int(ws[:4].view(torch.int32).cpu()[0])
+    assert listed > (1 << 20), listed                                  # the list did overflow
+    win = O.pool_windows(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    best = win.amax(-1)
+    rel_close(y.cpu().numpy(), torch.relu(best).float().numpy(), 1e-5, "pooled values")
+    chosen = win.gather(-1, am.cpu().long().unsqueeze(-1)).squeeze(-1)
+    live = best > 1e-2                                                 # where the ReLU passes (one channel cancels to ~-8e-4: gate closed)
+    assert int(live.sum()) > 0.9 * live.numel()
+    assert float(((best - chosen)[live] / best[live]).max()) <= 1e-5
 
 
 def test_conv_bwd_odd_shapes():
