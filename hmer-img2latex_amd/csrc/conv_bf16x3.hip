@@ -389,14 +389,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
 // read by two ds_read_b64 -- no im2col image, no per-tap splitting.  K = 9 taps x 4 = 36 -> 3 k-steps of 16 (taps
 // 9..11 carry zero weights); the filter bank (32 output channels x 48 k x 3 splits) sits in 36 registers per lane
 // for the whole kernel.  A workgroup walks the column tiles of an 8-row band (8 x 32 positions per tile, 2 M-tiles
-// per wave, 18 MFMAs per M-tile) with the next patch prefetched in registers; ~20 KB of LDS and ~165 registers
-// let three workgroups share a CU, so one's staging / epilogue hides behind the others' MFMAs (four would need
-// <= 128 registers: 45-99 spills, measured slower).  The pooled tile goes through LDS so that every store
+// per wave, 18 MFMAs per M-tile) with the next patch prefetched in registers.  The two M-tiles of a wave run one after
+// the other through ONE accumulator (`#pragma unroll 1`): 101-128 registers instead of 166, so FOUR workgroups share a CU
+// (~20 KB of LDS each) and one's staging / epilogue hides behind the others' MFMAs: 0.106 -> 0.095 ms at B=256, 78 ->
+// 66 us for the 64-image training forward.  The pooled tile goes through LDS so that every store
 // instruction writes 64-byte runs; storing 16 bytes per lane straight from the accumulators (v_permlane32_swap to
 // gather a lane's four columns) saves the transpose and a barrier but halves the run length: 0.106 -> 0.122 ms.
 // ---------------------------------------------------------------------------------------------------------------
 template <int CIN, bool AM = false>
-__global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
+__global__ __launch_bounds__(256, 4) void conv3x3_smallk_bf16x3_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     unsigned char* __restrict__ amax, int H, int W, int Cout, int Hp, int Wp, int tiles_x, int tiles_per_part,
     unsigned* __restrict__ fix) {
@@ -492,11 +493,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
         }
         __syncthreads();                                    // patch complete; out_s of the last tile consumed
         if (tx + 1 < tx_end) fetch(tx + 1);
-        f32x16 acc[2];
-#pragma unroll
+        // the two M-tiles one after the other (one accumulator, one set of operands live at a time: the register
+        // budget of four workgroups per CU); registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h (conv.hip
+        // layout), channel = lane & 31
+#pragma unroll 1
         for (int m = 0; m < 2; ++m) {
+            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 bf16x8 a[3];
@@ -510,12 +514,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
                 constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TI[t]], bw[s][TJ[t]], acc[m], 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TI[t]], bw[s][TJ[t]], acc, 0, 0, 0);
             }
-        }
-        // registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h (conv.hip layout); channel = lane & 31
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int pos = (wy * 2 + m) * 16 + wx * 8 + 2 * q + h;
@@ -523,17 +523,18 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallk_bf16x3_kernel(
                     float ov;
                     int bi;
                     bool near;
-                    pool_window(acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3], bv, ov, bi, near);
+                    pool_window(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], bv, ov, bi, near);
                     out_s[i * 65 + pos] = ov;
                     am_s[i * 68 + pos] = (unsigned char)bi;
                     const int fpy = (y0 >> 1) + wy * 2 + m, fpx = tx * 16 + wx * 8 + 2 * q + h;
                     if (near && fix && cb * 32 + i < Cout && fpy < Hp && fpx < Wp)
                         fix_append(fix, (((size_t)b * Cout + cb * 32 + i) * Hp + fpy) * Wp + fpx);
                 } else {
-                    const float v = fmaxf(fmaxf(acc[m][4 * q], acc[m][4 * q + 1]), fmaxf(acc[m][4 * q + 2], acc[m][4 * q + 3])) + bv;
+                    const float v = fmaxf(fmaxf(acc[4 * q], acc[4 * q + 1]), fmaxf(acc[4 * q + 2], acc[4 * q + 3])) + bv;
                     out_s[i * 65 + pos] = fmaxf(v, 0.f);
                 }
             }
+        }
         __syncthreads();                                    // pooled tile complete (and every wave is past its A reads)
         const int py0 = y0 >> 1, px0 = tx * 16;
         if ((Wp & 3) == 0 && py0 + 4 <= Hp && px0 + 16 <= Wp && (cb + 1) * 32 <= Cout) {
