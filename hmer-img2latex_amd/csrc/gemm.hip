@@ -309,10 +309,11 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(GemmArgs g, float* 
     const float* pa0 = A_KC ? g.A + (size_t)min(m0 + a_row0, g.M - 1) * g.lda : g.A + min(m0 + a_row0, g.M - 1);
     const float* pa1 = A_KC ? g.A + (size_t)min(m0 + a_row1, g.M - 1) * g.lda : g.A + min(m0 + a_row1, g.M - 1);
     const float* pw = W_KC ? g.W + (size_t)min(n0 + w_row, g.N - 1) * g.ldw : g.W + min(n0 + w_row, g.N - 1);
-    // three register stages: the loads of chunk c+2 are issued while chunk c computes (one chunk of MFMAs is only
-    // ~0.4 us, shorter than a memory round trip)
+    // two register stages, prefetch distance two: a stage's registers are free as soon as commit() has copied them to
+    // LDS, so the loads of chunk c+2 go straight back into the stage of chunk c (one chunk of MFMAs is only ~0.4 us,
+    // shorter than a memory round trip; a third stage cost 24 registers and three spills in the widest variant)
     struct Stage { float4 a[2][2], w[2]; };
-    Stage st0, st1, st2;
+    Stage st0, st1;
     auto load8 = [&](bool kc, const float* base, long ld, bool ok, int k, int kend, float4& lo, float4& hi) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         lo = z; hi = z;
@@ -434,10 +435,10 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(GemmArgs g, float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    auto step = [&](const Stage& cur, Stage& nxt2, long k0) {
+    auto step = [&](Stage& cur, long k0) {
         commit(cur);
         __syncthreads();
-        if (k0 + 2 * LBK < kf_end) fetch(nxt2, k0 + 2 * LBK);
+        if (k0 + 2 * LBK < kf_end) fetch(cur, k0 + 2 * LBK);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8_t a[MT][3], b[3];
@@ -463,10 +464,9 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(GemmArgs g, float* 
     };
     fetch(st0, kf_beg);
     if (kf_beg + LBK < kf_end) fetch(st1, kf_beg + LBK);
-    for (long k0 = kf_beg; k0 < kf_end; k0 += 3 * LBK) {
-        step(st0, st2, k0);
-        if (k0 + LBK < kf_end) step(st1, st0, k0 + LBK);
-        if (k0 + 2 * LBK < kf_end) step(st2, st1, k0 + 2 * LBK);
+    for (long k0 = kf_beg; k0 < kf_end; k0 += 2 * LBK) {
+        step(st0, k0);
+        if (k0 + LBK < kf_end) step(st1, k0 + LBK);
     }
     const int n = n0 + wn * 32 + i;
 #pragma unroll
