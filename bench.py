@@ -42,6 +42,7 @@ from img2latex_amd.pipeline import GreedyPipeline  # noqa: E402
 PEAK_HBM_GBS = 8000.0
 PEAK_FP32_TFLOPS = 157.3          # fp32 MFMA = fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0         # dense bf16 MFMA
+SUSTAINED_BF16_TFLOPS = 1820.0     # bare MFMA loops with random operands (profiles/micro/mfma_shapes.hip): the clock drops under toggling data
 
 
 def stage_costs(cfg, B, steps):
@@ -251,7 +252,9 @@ def main():
         roofline["encoder"] = dict(ms=round(e_ms, 4), frac_hbm=round(e_bytes / e_ms / 1e6 / PEAK_HBM_GBS, 4),
                                    frac_fp32=round(e_flops / e_ms / 1e9 / PEAK_FP32_TFLOPS, 4),
                                    frac_bf16_executed=round(6.0 * e_flops / e_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
-                                   note="algorithmic bytes / flops (SURVEY 8d); executed = 6 bf16 partial products per fp32 product")
+                                   frac_bf16_executed_of_sustained=round(6.0 * e_flops / e_ms / 1e9 / SUSTAINED_BF16_TFLOPS, 4),
+                                   note="algorithmic bytes / flops (SURVEY 8d); executed = 6 bf16 partial products per fp32 product; sustained = "
+                                        "what bare MFMA loops reach on random operands (1.82 of the nominal 2.5 PFLOP/s)")
     roofline["stages"] = stages
     roofline["measured_in"] = ("the timed region" if args.serial else
                                f"a serial pass of {args.steps} steps right after the timed region (one stream, whole chip per "
