@@ -474,6 +474,22 @@ def extra_modes(args, world, rank, dev, dist):
             return {"value": round(sum(len(q) for q in seqs) / dt, 1), "unit": "tokens/s", "cores": torch.get_num_threads(),
                     "kind": "port", "sample": f"4 of the {n} images, k={k}, beam search only (encoder excluded)"}
         name, conf = "beam-search decoded tokens/sec (best sequences)", {"workload": "cnn_lstm+attention beam k=5 (BASELINE configs[2])", "images_per_gpu": n, "beam": k, "max_length": T}
+
+        def after_check():
+            """Outside the timed region: the sequences are the REFERENCE's (tests/golden/primary_cfg3_beam.npz: 128 images,
+            k = 5, max_length 150 -- tokens + per-image decision margins read from the reference's own search)."""
+            path = os.path.join(REPO, "tests", "golden", "primary_cfg3_beam.npz")
+            if rank != 0 or T != 150 or not os.path.exists(path):
+                return "skipped (no fixture for this rank / length)"
+            d = np.load(path)
+            off = 0
+            for j in range(n):
+                want = [int(t) for t in d["ids"][j, :d["lens"][j]]]
+                if out[0][j] != want:
+                    assert d["min_gap"][j] < 1e-4, f"beam tokens of image {j} differ from the reference's"
+                    off += 1
+            assert off <= 0.05 * n
+            return f"tokens == reference fixture primary_cfg3_beam ({n} images; {off} leave it at a near-tie)"
     elif args.mode == "resnet":
         Bn, T = args.batch, args.seq
         cfg = synth.model_config()
@@ -665,6 +681,8 @@ def extra_modes(args, world, rank, dev, dist):
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.mode == "resnet" else ("u8" if args.mode == "preprocess" else ("int32" if args.mode == "metrics" else "f32")),
                 "data": "synthetic", "config": conf,
                 "roofline": roof(elapsed / args.steps * 1e3)}
+        if args.mode == "beam":
+            line["ids_check"] = after_check()
         if world == 1 and not args.no_cpu_baseline and cpu_base is not None:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             torch.set_num_threads(host_cores())

@@ -63,7 +63,17 @@ CONFIGS = {
     "primary": (dict(), dict(seed=42, out_scale=12.0, enc_scale=16.0, end_clock=(0.05, 12.0, 6.0))),
     "secondary": (dict(embedding_dim=512, hidden_dim=512, lstm_layers=2, attention=True),
                   dict(seed=43, out_scale=12.0, enc_scale=16.0, end_clock=(0.05, 12.0, 6.0))),
+    # the reference's OWN shapes (r03): its CNN test vector (4,1,64,800) -> (4,256) (tests/test_encoder.py:11-42,
+    # constructor defaults for everything else) ...
+    "ref_test_64x800": (dict(channels=1, img_height=64, img_width=800),
+                        dict(seed=44, out_scale=12.0, enc_scale=16.0, end_clock=(0.05, 12.0, 6.0))),
+    # ... and the shipped cnn_lstm configuration (configs/config.yaml:30-50): 1x128x800, E = Hd = 512, L = 2, attention;
+    # Flatten feeds the Linear K = 128 * 16 * 100 = 204 800 features
+    "shipped_128x800": (dict(channels=1, img_height=128, img_width=800, embedding_dim=512, hidden_dim=512,
+                             lstm_layers=2, attention=True),
+                        dict(seed=45, out_scale=12.0, enc_scale=16.0, end_clock=(0.05, 12.0, 6.0))),
 }
+BIG = ("primary", "secondary", "ref_test_64x800", "shipped_128x800")
 
 
 def build_reference(cfg, np_sd):
@@ -224,6 +234,78 @@ def run_cfg2(fname, cfg, sd_kw):
     print(fname, "ok", arr.shape, "min margin", margins.min(), "END count", int((arr == END).sum()))
 
 
+def traced_beam_search(ref, image, k, max_length):
+    """Run the reference's UNMODIFIED Seq2SeqModel.inference(beam_size=k) on one image and read, through a trace
+    function on the `_beam_search` frame (seq2seq.py:234-298), what the method does not return: the winning beam's
+    score (:286-290) and, per step, the smallest gap between neighbours among the k + 1 best candidate scores right
+    after the sort (:279-280) -- the decisions an fp32 reassociation of the logits could flip."""
+    import inspect
+    fn = Seq2SeqModel._beam_search
+    code = fn.__code__
+    src, first = inspect.getsourcelines(fn)
+    cut_line = first + next(i for i, ln in enumerate(src) if "beams = candidates[:beam_size]" in ln)
+    info = {"score": None, "gap": float("inf"), "final_gap": float("inf"), "steps": 0}
+
+    def local(frame, event, arg):
+        if event == "line" and frame.f_lineno == cut_line:
+            sc = [c["score"] for c in frame.f_locals["candidates"][:k + 1]]
+            info["steps"] += 1
+            for a, b in zip(sc[:-1], sc[1:]):
+                info["gap"] = min(info["gap"], a - b)
+        elif event == "return":
+            best = frame.f_locals.get("best_beam")
+            if best is not None:
+                info["score"] = float(best["score"])
+                done = sorted((c["score"] for c in frame.f_locals["completed"]), reverse=True)
+                if len(done) > 1:
+                    info["final_gap"] = done[0] - done[1]
+        return local
+
+    def tracer(frame, event, arg):
+        return local if frame.f_code is code else None
+
+    sys.settrace(tracer)
+    try:
+        seq = ref.inference(image, START, END, max_length=max_length, beam_size=k)
+    finally:
+        sys.settrace(None)
+    return seq, info
+
+
+def run_cfg3_beam(fname, cfg, sd_kw, n, k, T, seed=1234):
+    """BASELINE configs[2] at ITS size: n single-image beam searches (k beams, up to T steps, attention on) by the
+    reference, tokens + winning score + decision margins per image."""
+    imgs = torch.from_numpy(synth.make_images(n, cfg, seed=seed))
+    ref = build_reference(cfg, synth.make_state_dict(cfg, **sd_kw))
+    seqs, scores, gaps, fgaps, steps = [], [], [], [], []
+    with torch.no_grad():
+        for j in range(n):
+            s, info = traced_beam_search(ref, imgs[j:j + 1], k, T)
+            seqs.append(s)
+            scores.append(info["score"])
+            gaps.append(info["gap"])
+            fgaps.append(info["final_gap"])
+            steps.append(info["steps"])
+        enc = ref.encoder(imgs)
+    arr = np.full((n, max(len(s) for s in seqs) + 1), -1, dtype=np.int16)
+    for j, s in enumerate(seqs):
+        arr[j, :len(s)] = s
+    np.savez_compressed(os.path.join(OUT, fname + ".npz"), ids=arr, lens=np.array([len(s) for s in seqs]),
+                        scores=np.array(scores, dtype=np.float64), min_gap=np.array(gaps), final_gap=np.array(fgaps),
+                        steps=np.array(steps), k=np.array(k), max_length=np.array(T), image_seed=np.array(seed),
+                        sd_kw_json=np.array(json.dumps(sd_kw)), cfg_json=np.array(json.dumps(cfg)),
+                        enc_checksum=np.array(synth.checksum(enc.numpy())))
+    print(fname, "ok", arr.shape, "steps", min(steps), "..", max(steps), "min gap", min(gaps), "min final gap", min(fgaps))
+
+
+CFG3_BEAM = {
+    # = bench.py --mode beam: 128 images, k = 5, max_length 150, attention, END clock (searches end at row-dependent steps)
+    "primary_cfg3_beam": (dict(seed=42, out_scale=12.0, enc_scale=16.0, end_clock=(0.05, 12.0, 6.0)), 128, 5, 150),
+    # END never wins: every search runs all 150 steps with 5 live beams (completed stays empty -> beams[0])
+    "primary_cfg3_beam_noend": (dict(seed=42, out_scale=8.0, enc_scale=16.0), 32, 5, 150),
+}
+
+
 def run_init_parity():
     """Same torch.manual_seed -> same default init as the reference constructors
     (parameter creation order encoder.py:78-106, decoder.py:69-90)."""
@@ -244,9 +326,13 @@ if __name__ == "__main__":
     for name, (ckw, skw) in CONFIGS.items():
         if only and name not in only:
             continue
-        ref, cfg, _ = run_config(name, ckw, skw, big=name in ("primary", "secondary"))
+        ref, cfg, _ = run_config(name, ckw, skw, big=name in BIG)
         if name == "primary":
             for fname, kw in CFG2_SD_KW.items():
                 run_cfg2(fname, cfg, kw)
+    for fname, (kw, n, k, T) in CFG3_BEAM.items():
+        if only and fname not in only:
+            continue
+        run_cfg3_beam(fname, synth.model_config(attention=True), kw, n, k, T)
     if not only:
         run_init_parity()

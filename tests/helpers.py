@@ -10,7 +10,9 @@ from img2latex_amd import synth
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 START, END, PAD = synth.START, synth.END, synth.PAD
 SMALL = ["tiny_l1", "tiny_l2_attn", "odd_dims"]
-ALL = SMALL + ["primary", "secondary"]
+WIDE = ["ref_test_64x800", "shipped_128x800"]      # the reference's own shapes (tests/test_encoder.py:11-42, configs/config.yaml:30-50)
+BIG = ["primary", "secondary"] + WIDE               # fixtures that hold samples instead of whole tensors, T = 24
+ALL = SMALL + BIG
 
 
 def load(name):

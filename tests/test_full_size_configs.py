@@ -271,3 +271,40 @@ def test_cfg4_resnet50_full_size():
     record("cfg4 resnet50 B=256 worst conv layer vs independent fp32 [rel to layer max]", worst)
     print(f"\n[cfg4 resnet50 B=256] trunk rel err vs fp32 oracle (16 images) {e_feat:.2e}, encoder {e_out:.2e}; worst "
           f"per-layer max err relative to the layer's max {worst:.2e} over 53 conv launches")
+
+
+def test_resnet50_reference_test_vector_64x800():
+    """The reference's ResNet test vector (tests/test_encoder.py:45-76): (4,3,64,800) -> (4,256).  The final feature
+    map is 2 x 25 positions (800 / 32: not a multiple of 4), so every layer's GEMM has a ragged last M tile at this
+    width.  The shape is the reference's assertion; the values are UNPINNED and checked against the fp32
+    restatement and, per conv launch, against an independent fp32 computation of the same layer."""
+    import resnet_oracle as RO
+    from img2latex_amd.model import ResNetEncoder
+    torch.backends.cuda.matmul.allow_tf32 = False
+    enc = ResNetEncoder(img_height=64, img_width=800, channels=3, embedding_dim=256)
+    shapes = [(k, tuple(v.shape)) for k, v in enc.state_dict().items()]
+    np_sd = synth.make_resnet_state_dict(shapes, seed=6)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in np_sd.items()}, strict=True)
+    enc = enc.to(DEV).eval()
+    x = torch.from_numpy(synth.uniform(77, "images", (4, 3, 64, 800), -1.0, 1.0))
+    with torch.no_grad():
+        enc.trace = []
+        out = enc(x.to(DEV))
+        trace, enc.trace = enc.trace, None
+        assert tuple(out.shape) == (4, 256)
+        sd = {"encoder." + k: torch.from_numpy(v) for k, v in np_sd.items()}
+        want = RO.resnet_encoder(sd, "resnet50", x)
+        e_out = float((out.cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))
+        assert e_out <= 4e-2, e_out
+        assert len(trace) == 53
+        worst = 0.0
+        for i, (conv, bn, xi, res, y, relu, nchw) in enumerate(trace):
+            ref = _layer_reference(conv, bn, xi, res, relu, nchw)
+            gotl = y.float()
+            assert gotl.shape == ref.shape and torch.isfinite(gotl).all(), i
+            excess = float(((gotl - ref).abs() - 2.0 ** -7 * ref.abs()).max())
+            worst = max(worst, float((gotl - ref).abs().max()) / max(float(ref.abs().max()), 1e-30))
+            assert excess <= 2e-3 * max(1.0, float(ref.abs().max())), (i, conv, excess)
+    assert tuple(trace[-1][4].shape[1:3]) == (2, 25)
+    record("resnet50 (4,3,64,800) encoder output vs fp32 oracle [rel to max(1,|ref|)]", e_out)
+    record("resnet50 (4,3,64,800) worst conv layer vs independent fp32 [rel to layer max]", worst)

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 import img2latex_oracle as O
 from conftest import record
-from helpers import (ALL, PAD, SMALL, adam_first_step_allowance, check_decisions, hip_decisions, images, load, sample,
+from helpers import (ALL, BIG, PAD, SMALL, adam_first_step_allowance, check_decisions, hip_decisions, images, load, sample,
                      torch_state_dict)
 from img2latex_amd import _lib, synth
 from img2latex_amd.model import Seq2SeqModel
@@ -305,7 +305,7 @@ def test_train_step_vs_reference_golden(name):
     loss, per-parameter gradient norms, total norm before clipping, parameters after one Adam step."""
     from img2latex_amd.training import TrainStep
     d, cfg, m = build(name)
-    big = name in ("primary", "secondary")
+    big = name in BIG
     T = 24 if big else 12
     forms = torch.from_numpy(synth.make_formulas(4, T, cfg["vocab_size"], seed=777, min_len=5)).to(DEV)
     x = images(cfg, device=DEV)
@@ -391,7 +391,7 @@ def test_reference_trainer_loop_over_the_dropin_model(name, amp):
     kernels are not autocast-eligible ops, so they keep computing in fp32 (>= the reference's precision) and the
     loss-scaled backward must land on the same parameters."""
     d, cfg, m = build(name)
-    big = name in ("primary", "secondary")
+    big = name in BIG
     T = 24 if big else 12
     formulas = torch.from_numpy(synth.make_formulas(4, T, cfg["vocab_size"], seed=777, min_len=5)).to(DEV)    # int64
     images_ = images(cfg, device=DEV)

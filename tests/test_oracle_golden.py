@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import img2latex_oracle as O
-from helpers import ALL, END, PAD, SMALL, START, images, load, padded_to_lists, sample, torch_state_dict
+from helpers import ALL, BIG, END, PAD, SMALL, START, images, load, padded_to_lists, sample, torch_state_dict
 from img2latex_amd import synth
 
 TOL = 1e-6
@@ -87,6 +87,25 @@ def test_beam_ids(name):
     assert np.array_equal(np.array(fb), d["g4_fallback_ids"])
 
 
+@pytest.mark.parametrize("fname,rows", [("primary_cfg3_beam", (0, 17, 127)), ("primary_cfg3_beam_noend", (5,))])
+def test_cfg3_beam_full_length(fname, rows):
+    """BASELINE configs[2] at its length (k = 5, max_length 150, attention): the oracle against the reference's
+    tokens AND winning score (read from the reference's `_beam_search` frame by make_golden.traced_beam_search) on a
+    few of the fixture's images -- the GPU test covers all of them."""
+    d, cfg, sd_kw = load(fname)
+    sd = O.to_torch_sd(synth.make_state_dict(cfg, **sd_kw))
+    x = torch.from_numpy(synth.make_images(len(d["lens"]), cfg, seed=int(d["image_seed"])))
+    with torch.no_grad():
+        enc = O.cnn_encoder(sd, cfg, x)
+        assert abs(synth.checksum(enc.numpy()) - float(d["enc_checksum"])) <= 1e-6 * abs(float(d["enc_checksum"]))
+        for j in rows:
+            one = O.cnn_encoder(sd, cfg, x[j:j + 1])          # the reference encodes each image alone (seq2seq.py:163)
+            seq, score = O.beam_search(sd, cfg, one, START, END, int(d["max_length"]), int(d["k"]), return_score=True)
+            assert seq == list(map(int, d["ids"][j, :d["lens"][j]])), (fname, j)
+            # a score is a float64 sum of up to 150 fp32 log-probabilities, each within ~1e-7 of nn.LSTM's
+            assert abs(score - float(d["scores"][j])) <= TOL * max(1.0, abs(score)), (fname, j, score, float(d["scores"][j]))
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_predictor_loop_ids(name):
     d, cfg, _ = load(name)
@@ -103,7 +122,7 @@ def test_predictor_loop_ids(name):
 def test_train_step(name):
     d, cfg, _ = load(name)
     sd = torch_state_dict(name)
-    big = name in ("primary", "secondary")
+    big = name in BIG
     T = 24 if big else 12
     forms = torch.from_numpy(synth.make_formulas(4, T, cfg["vocab_size"], seed=777, min_len=5))
     names = json.loads(str(d["g6_param_names"]))
