@@ -84,14 +84,35 @@ def main():
                     help="time the two-stream batch pipeline (encoder of batch i+1 beside the decode of batch i, "
                          "GreedyPipeline, row-per-workgroup decode kernel); a second, serial pass of the same number of "
                          "steps provides the undisturbed per-kernel times for the roofline object")
+    ap.add_argument("--launch-probe", action="store_true",
+                    help="rendezvous check only (CPU, gloo): every rank all-reduces its rank number, rank 0 prints "
+                         "{n_gpus, ranks_seen}; exercises the self-launch path of `--gpus N` without a GPU")
     args = ap.parse_args()
     args.serial = not args.pipelined
 
+    if args.launch_probe:
+        os.environ.setdefault("I2L_DIST_BACKEND", "gloo")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU
+        # yet (device_count() does not initialise it), and the ranks are CHILD processes, never an exec of this one
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a line whose n_gpus "
+                         "is not what was asked for")
+    if args.launch_probe:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.tensor([float(rank + 1)])
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": float(seen.item()), "probe": True}), flush=True)
+        dist.destroy_process_group()
+        return
     local = local % max(1, torch.cuda.device_count())       # rehearsals may put several ranks on one card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -220,10 +241,16 @@ def main():
                            frac_fp32=round(c["flops"] / ms / 1e9 / PEAK_FP32_TFLOPS, 4),
                            frac_hbm=round(c["bytes"] / ms / 1e6 / PEAK_HBM_GBS, 4)))
     dom = max(stages, key=lambda s: s["ms"])
-    traffic = None
+    # HBM bytes per launch of the dominant kernel: hardware counters cannot be read inside this run (rocprofv3 --pmc
+    # is its own pass and serialises the kernels), so `traffic` is the figure of the LATEST committed counter collection
+    # of this same command (profiles/collect.sh -> profiles/traffic.json), and `traffic_from` says which one
+    traffic = traffic_from = None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(dom["kernel"])
+        tj = json.load(open(tpath))
+        traffic = tj.get(dom["kernel"])
+        traffic_from = tj.get("_collection", "profiles/traffic.json (rocprofv3 --pmc passes of `python bench.py`, collection "
+                                             "not recorded)") + " -- a separate counter pass, not this timed run"
     # What bounds the dominant kernel.  The decode loop's matrix work (1.835 MFLOP/token algorithmic) is
     # priced against the fp32 peak as the contract asks, but the kernel is NOT arithmetic-bound: it runs on the vector
     # ALUs (v_pk_fma_f32, no MFMA), executes only 0.786 MFLOP/token (the W_ih [emb | enc] half of the gate GEMM is
@@ -231,14 +258,15 @@ def main():
     # four workgroups of a group through L2: a latency chain.  The conv blocks / FC run on the bf16 matrix cores (3-way
     # split operands, 6 bf16 products per fp32 product).
     roofline = dict(kernel=dom["kernel"], achieved=dom["tflops"], peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
-                    frac=round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), traffic=traffic, launch_ms=dom["ms"])
+                    frac=round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), traffic=traffic, traffic_from=traffic_from,
+                    launch_ms=dom["ms"])
     if dom["kernel"] == "decode":
-        executed = 2.0 * (4 * cfg["hidden_dim"] * cfg["hidden_dim"] * (2 * cfg["lstm_layers"] - 1)
-                          + cfg["hidden_dim"] * cfg["vocab_size"]) * B * executed_steps_holder[0]
+        run_flops = 2.0 * (4 * cfg["hidden_dim"] * cfg["hidden_dim"] * (2 * cfg["lstm_layers"] - 1)
+                           + cfg["hidden_dim"] * cfg["vocab_size"]) * B * executed_steps_holder[0]
         roofline.update(bound="latency", kernel="decode_group_kernel", priced_against="mfma (fp32 peak; the kernel itself "
                         "uses v_pk_fma_f32 on the vector ALUs, same 157.3 TFLOP/s peak)",
-                        executed_tflops=round(executed / dom["ms"] / 1e9, 3),
-                        frac_executed=round(executed / dom["ms"] / 1e9 / PEAK_FP32_TFLOPS, 4),
+                        executed_tflops=round(run_flops / dom["ms"] / 1e9, 3),
+                        frac_executed=round(run_flops / dom["ms"] / 1e9 / PEAK_FP32_TFLOPS, 4),
                         us_per_decode_step=round(dom["ms"] * 1e3 / executed_steps_holder[0], 3),
                         note="per-step latency chain (two in-group L2 exchanges + LSTM cell), not arithmetic: "
                              "frac = algorithmic 1.835 MFLOP/token, frac_executed = the 0.786 MFLOP/token the kernel runs")
@@ -301,6 +329,31 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this script, one rank per GPU, with the
+    rendezvous variables torch.distributed.run would set (127.0.0.1, a free port).  Rank 0's stdout (the ONE JSON line)
+    is passed through; the exit code is the worst of the ranks'.  Refuses when fewer than N GPUs are visible -- unless
+    I2L_DIST_BACKEND=gloo, the one-card rehearsal in which several ranks share a device."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("I2L_DIST_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible; not running a smaller job under that name",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    return max((abs(c) for c in codes), default=0)
 
 
 def golden_ids_check(ids_host, B, T, rank):
@@ -668,6 +721,30 @@ def extra_modes(args, world, rank, dev, dist):
         tot = torch.tensor([units], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         units = float(tot.item())
+    if args.mode == "train" and dist is not None:
+        # the gradient all-reduce alone (the flat buffer [grads, loss sum, count]: 46.5 MB), outside the
+        # timed region, HIP events on the stream the collective is enqueued from; bus bandwidth = 2 (N-1)/N x bytes / t
+        # (what each xGMI link pair carries in a ring / the direct reduce-scatter + all-gather schedule)
+        buf = torch.zeros_like(ts.flat_grads)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 20
+        ev[0].record()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ar = torch.tensor([ev[0].elapsed_time(ev[1]) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        ar_ms, nbytes = float(ar.item()), buf.numel() * 4
+        conf.update(all_reduce_ms=round(ar_ms, 4), all_reduce_payload_mb=round(nbytes / 1e6, 2),
+                    all_reduce_algbw_gbs=round(nbytes / ar_ms / 1e6, 1),
+                    all_reduce_busbw_gbs=round(2.0 * (world - 1) / world * nbytes / ar_ms / 1e6, 1),
+                    all_reduce_backend=dist.get_backend(),
+                    all_reduce_note="alone on the chip; inside the step it is issued in two pieces and the first "
+                                    "(99 % of the bytes) overlaps the conv backward (dp.OverlappedAllReduce)")
     if args.mode == "resnet":
         ms = float(np.median(conf["encoder_ms"][-args.steps:]))
         conf["encoder_ms"] = round(ms, 4)

@@ -56,6 +56,15 @@ class OverlappedAllReduce:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def start_early(self) -> None:
+        """Exactly one finish() (TrainStep.apply) must follow each start_early() (TrainStep.forward_backward): the
+        buffer is being reduced in place.  A second start_early() without it -- a forward_backward() repeated after an
+        exception, or a caller only inspecting gradients -- first waits for the pending piece, so that the next
+        backward does not overwrite memory a collective is still reading; the buffer then holds the REDUCED early
+        gradients of the abandoned step, which the new backward overwrites (gradient accumulation across several
+        forward_backward() calls is not supported under data parallelism)."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
         if self._active() and 0 < self.split < self.flat.numel():
             import torch.distributed as dist
             self._work = dist.all_reduce(self.flat[: self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -132,8 +132,16 @@ class TrainStep:
                     skipped=self.stats[3])
 
     def applied_steps(self) -> int:
-        """Optimizer steps actually applied (host sync): step_count minus the skipped, non-finite ones."""
+        """Optimizer steps actually applied (host sync): step_count minus the skipped, non-finite ones.  Called at
+        checkpoint / logging time; warns when every step since the last call was skipped (gradients that STAY
+        non-finite are divergence, not a one-off timeout -- the silent no-op updates would otherwise go unnoticed)."""
         skipped = int(self._opt_ws[-256:-252].view(torch.int32).item())
+        last_steps, last_skipped = getattr(self, "_last_counts", (0, 0))
+        if self.step_count - last_steps >= 8 and skipped - last_skipped == self.step_count - last_steps:
+            import warnings
+            warnings.warn(f"img2latex_amd: all {self.step_count - last_steps} optimizer steps since the last check were "
+                          "skipped (non-finite gradients): the run has diverged or the grouped kernels keep timing out")
+        self._last_counts = (self.step_count, skipped)
         return self.step_count - skipped
 
     # ------------------------------------------------------------------ checkpoint compatibility
@@ -150,7 +158,8 @@ class TrainStep:
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "decoupled_weight_decay": False, "params": params}
-        return {"state": state if self.step_count > 0 else {}, "param_groups": [group]}
+        # like torch's Adam under GradScaler, the state stays empty until an update has actually been APPLIED
+        return {"state": state if applied > 0 else {}, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, sd: Dict) -> None:
         """Inverse of the above (trainer.py:255, resume from a reference checkpoint)."""

@@ -32,7 +32,9 @@ def per_kernel(path, counter):
                 acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
-out = {"_note": __doc__.split("\n\n")[1].replace("\n", " "), "raw_kb": {}, "_kernels": {}}
+out = {"_note": __doc__.split("\n\n")[1].replace("\n", " "),
+       "_collection": f"profiles/{rnd}/pmc_fetch_size_{tag}.csv + pmc_write_size_{tag}.csv (rocprofv3 --pmc passes of `python bench.py`, {rnd} {tag})",
+       "raw_kb": {}, "_kernels": {}}
 for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     avg = per_kernel(f"{src}/{sub}/p_counter_collection.csv", counter)
     with open(f"{dst}/pmc_{counter.lower()}_{tag}.csv", "w") as f:

@@ -134,3 +134,36 @@ def test_resnet_encoder_surface():
         ResNetEncoder(model_name="resnet42")
     m = Seq2SeqModel("resnet_lstm", 50, {"model_name": "resnet18", "embedding_dim": 32}, {"hidden_dim": 64})
     assert m.model_type == "resnet_lstm" and any(k.startswith("encoder.resnet.7.") for k in m.state_dict())
+
+
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "I2L_DIST_BACKEND")):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself and rank 0 prints ONE line with
+    n_gpus = N (--launch-probe: the rendezvous only, gloo on the CPU -- the same code path the GPU modes take)."""
+    import json
+    r = _run_bench(["--gpus", "3", "--launch-probe"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["ranks_seen"] == 6.0          # ranks 0, 1, 2 all took part
+
+
+def test_bench_refuses_a_mismatched_world():
+    """Never a line whose n_gpus is not what was asked for: a launcher-provided WORLD_SIZE that differs from --gpus
+    is refused (also WORLD_SIZE=1 with --gpus 2, which r02 silently ran as one rank), and without enough visible GPUs
+    the self-launch refuses as well instead of running a smaller job."""
+    r = _run_bench(["--gpus", "2", "--launch-probe"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+        assert r.returncode == 2 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
