@@ -23,6 +23,15 @@ double lanczos_filter(double x) {
     if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
     return 0.0;
 }
+// Pillow's BICUBIC (Keys, a = -0.5, support 2): what Image.resize() uses when no filter is named (predictor.py:439)
+double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+double filter_support(int filter) { return filter == I2L_FILTER_BICUBIC ? 2.0 : 3.0; }
 
 // value of converted-mode pixel (y, x, band c) of the source image: utils.py:45-49 img.convert("L" / "RGB")
 __device__ __forceinline__ int src_px(const uint8_t* __restrict__ img, int w, int src_c, int out_c, int y, int x, int c) {
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
             }
             float t = __fdiv_rn((float)v, 255.0f);                          // utils.py:68
             if (normalize) {
-                if (out_c == 1) t = __fsub_rn(__fmul_rn(t, 2.0f), 1.0f);   // utils.py:74
+                if (out_c == 1 || normalize == 2) t = __fsub_rn(__fmul_rn(t, 2.0f), 1.0f);   // utils.py:74; predictor.py:449-451
                 else t = __fdiv_rn(__fsub_rn(t, mean[c]), stdv[c]);         // utils.py:77-79
             }
             out[(((size_t)b * out_c + c) * out_h + y) * out_w + x] = t;
@@ -96,23 +105,56 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
     }
 }
 
-}  // namespace
-
-// ---- host: Pillow's precompute_coeffs + normalize_coeffs_8bpc for the LANCZOS filter over the full source range
-extern "C" int i2l_lanczos_ksize(int in_size, int out_size) {
-    if (in_size <= 0 || out_size <= 0) return 0;
-    double filterscale = (double)((float)in_size - 0.0f) / out_size;
-    if (filterscale < 1.0) filterscale = 1.0;
-    return (int)ceil(3.0 * filterscale) * 2 + 1;
+// torch.nn.functional.interpolate(mode="bilinear", align_corners=False) of fp32 planes (predictor.py:483-491):
+// source index = max(0, (dst + 0.5) * in / out - 0.5), the neighbour clamped to the last sample
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
+                                                       int ih, int iw, int oh, int ow) {
+    const float sh = (float)ih / (float)oh, sw = (float)iw / (float)ow;
+    const long total = planes * oh * ow;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = (int)(idx % ow), y = (int)((idx / ow) % oh);
+        const long p = idx / ((long)ow * oh);
+        const float fy = fmaxf(__fsub_rn(__fmul_rn(sh, (float)y + 0.5f), 0.5f), 0.0f);
+        const float fx = fmaxf(__fsub_rn(__fmul_rn(sw, (float)x + 0.5f), 0.5f), 0.0f);
+        const int y0 = min((int)fy, ih - 1), x0 = min((int)fx, iw - 1);
+        const int y1 = min(y0 + 1, ih - 1), x1 = min(x0 + 1, iw - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* src = in + p * (long)ih * iw;
+        const float top = __fadd_rn(__fmul_rn(1.0f - lx, src[(long)y0 * iw + x0]), __fmul_rn(lx, src[(long)y0 * iw + x1]));
+        const float bot = __fadd_rn(__fmul_rn(1.0f - lx, src[(long)y1 * iw + x0]), __fmul_rn(lx, src[(long)y1 * iw + x1]));
+        out[idx] = __fadd_rn(__fmul_rn(1.0f - ly, top), __fmul_rn(ly, bot));
+    }
 }
 
-extern "C" int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out) {
+}  // namespace
+
+extern "C" int i2l_resize_bilinear_f32(const float* in, float* out, int64_t planes, int in_h, int in_w, int out_h,
+                                       int out_w, i2l_stream_t stream) {
+    if (!in || !out || planes <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return I2L_ERR_ARG;
+    long total = (long)planes * out_h * out_w;
+    int bx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(bilinear_kernel, dim3(bx), dim3(256), 0, i2l_s(stream), in, out, (long)planes, in_h, in_w, out_h, out_w);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+// ---- host: Pillow's precompute_coeffs + normalize_coeffs_8bpc for the LANCZOS / BICUBIC filter over the full source range
+extern "C" int i2l_resample_ksize(int filter, int in_size, int out_size) {
+    if (in_size <= 0 || out_size <= 0 || (filter != I2L_FILTER_LANCZOS && filter != I2L_FILTER_BICUBIC)) return 0;
+    double filterscale = (double)((float)in_size - 0.0f) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    return (int)ceil(filter_support(filter) * filterscale) * 2 + 1;
+}
+extern "C" int i2l_lanczos_ksize(int in_size, int out_size) { return i2l_resample_ksize(I2L_FILTER_LANCZOS, in_size, out_size); }
+
+extern "C" int i2l_resample_coeffs(int filter, int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out) {
     if (in_size <= 0 || out_size <= 0 || !bounds_out || !kk_out) return I2L_ERR_ARG;
+    if (filter != I2L_FILTER_LANCZOS && filter != I2L_FILTER_BICUBIC) return I2L_ERR_UNSUPPORTED;
     const float in0 = 0.0f, in1 = (float)in_size;
     double filterscale, scale;
     filterscale = scale = (double)(in1 - in0) / out_size;
     if (filterscale < 1.0) filterscale = 1.0;
-    const double support = 3.0 * filterscale;
+    const double support = filter_support(filter) * filterscale;
     const int ksize = (int)ceil(support) * 2 + 1;
     const double ss = 1.0 / filterscale;
     for (int xx = 0; xx < out_size; ++xx) {
@@ -127,7 +169,8 @@ extern "C" int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out
         if (xmax > 512) return I2L_ERR_UNSUPPORTED;           // down-scaling by more than ~80x
         int x;
         for (x = 0; x < xmax; ++x) {
-            const double w = lanczos_filter((x + xmin - center + 0.5) * ss);
+            const double arg = (x + xmin - center + 0.5) * ss;
+            const double w = filter == I2L_FILTER_BICUBIC ? bicubic_filter(arg) : lanczos_filter(arg);
             k[x] = w;
             ww += w;
         }
@@ -141,6 +184,10 @@ extern "C" int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out
         bounds_out[2 * xx + 1] = xmax;
     }
     return I2L_OK;
+}
+
+extern "C" int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out) {
+    return i2l_resample_coeffs(I2L_FILTER_LANCZOS, in_size, out_size, bounds_out, kk_out);
 }
 
 extern "C" int i2l_preprocess_images(const uint8_t* pixels, const i2l_resize_plan* plans, const int32_t* tables, int n,

@@ -31,21 +31,27 @@ class ResizePlan(ctypes.Structure):
 
 
 @functools.lru_cache(maxsize=4096)
-def _coeffs(in_size: int, out_size: int) -> Tuple[int, np.ndarray, np.ndarray]:
+def _coeffs(in_size: int, out_size: int, flt: int = _lib.FILTER_LANCZOS) -> Tuple[int, np.ndarray, np.ndarray]:
     L = _lib.lib()
-    ksize = L.i2l_lanczos_ksize(in_size, out_size)
+    ksize = L.i2l_resample_ksize(flt, in_size, out_size)
     if ksize <= 0:
         raise ValueError(f"cannot resample {in_size} -> {out_size}")
     bounds = np.zeros((out_size, 2), np.int32)
     kk = np.zeros((out_size, ksize), np.int32)
-    _lib.check(L.i2l_lanczos_coeffs(in_size, out_size, bounds.ctypes.data, kk.ctypes.data), "lanczos_coeffs")
+    _lib.check(L.i2l_resample_coeffs(flt, in_size, out_size, bounds.ctypes.data, kk.ctypes.data), "resample_coeffs")
     return ksize, bounds, kk
 
 
 def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (64, 800), channels: int = 1,
-                     normalize: bool = True, device=None) -> torch.Tensor:
+                     normalize=True, device=None, keep_aspect: bool = True, resample: str = "lanczos") -> torch.Tensor:
     """`load_image` for already decoded images: uint8 arrays (H, W) ["L"] or (H, W, 3) ["RGB"], any sizes.
-    Returns (n, channels, img_size[0], img_size[1]) float32 on the device."""
+    Returns (n, channels, img_size[0], img_size[1]) float32 on the device.
+
+    ``keep_aspect=False, resample="bicubic", normalize="symmetric"`` is the PIL.Image branch of the reference's
+    ``Predictor._prepare_image`` instead (predictor.py:432-451): ``image.resize((W, H))`` with Pillow's default filter
+    straight to the target size, then ``x / 255 * 2 - 1`` on every channel."""
+    flt = {"lanczos": _lib.FILTER_LANCZOS, "bicubic": _lib.FILTER_BICUBIC}[resample]
+    normalize = 2 if normalize == "symmetric" else int(bool(normalize))
     if channels not in (1, 3):
         raise ValueError("channels must be 1 or 3")
     if not torch.cuda.is_available():
@@ -67,14 +73,14 @@ def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (
         h, w = img.shape[:2]
         if h == 0 or w == 0:
             raise ValueError("empty image")
-        new_w = int(round(out_h * (w / h)))                       # transforms.py:33-36
+        new_w = int(round(out_h * (w / h))) if keep_aspect else out_w   # transforms.py:33-36 / predictor.py:439
         if new_w <= 0:
             raise ValueError(f"image {i} ({h}x{w}) collapses to zero width at height {out_h}")
         p = plans[i]
         p.src_offset, p.src_h, p.src_w, p.src_c = p_off, h, w, 1 if img.ndim == 2 else 3
         p.new_w, p.need_h, p.need_v = new_w, int(new_w != w), int(out_h != h)
-        kh_k, bh, kh = _coeffs(w, new_w)
-        kv_k, bv, kv = _coeffs(h, out_h)
+        kh_k, bh, kh = _coeffs(w, new_w, flt)
+        kv_k, bv, kv = _coeffs(h, out_h, flt)
         ybox_first = int(bv[0, 0])
         ybox_last = int(bv[out_h - 1, 0] + bv[out_h - 1, 1])
         if p.need_h:                                              # Resample.c: shift bounds for the vertical pass
@@ -101,7 +107,7 @@ def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (
     out = torch.empty((n, channels, out_h, out_w), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().i2l_preprocess_images(d_pixels.data_ptr(), d_plans.data_ptr(), d_tables.data_ptr(), n,
-                                                    max_tmp_px, channels, out_h, out_w, int(bool(normalize)),
+                                                    max_tmp_px, channels, out_h, out_w, normalize,
                                                     ws.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "preprocess_images")
     return out
 
@@ -122,6 +128,20 @@ def load_image(image_path: str, img_size: Tuple[int, int] = (64, 800), channels:
     except Exception:                                             # utils.py:84-90
         dev = torch.device("cuda", torch.cuda.current_device())
         return torch.zeros((channels, img_size[0], img_size[1]), device=dev)
+
+
+def resize_bilinear(t: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """``torch.nn.functional.interpolate(t, size, mode="bilinear", align_corners=False)`` of a (..., H, W) fp32 device
+    tensor on the HIP kernel (the tensor branch of Predictor._prepare_image, predictor.py:483-491)."""
+    if not t.is_cuda:
+        raise RuntimeError("img2latex_amd: resize_bilinear needs a tensor on the ROCm device; there is no CPU fallback")
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty(t.shape[:-2] + (int(size[0]), int(size[1])), dtype=torch.float32, device=t.device)
+    planes = int(np.prod(t.shape[:-2])) if t.dim() > 2 else 1
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.lib().i2l_resize_bilinear_f32(t.data_ptr(), out.data_ptr(), planes, t.shape[-2], t.shape[-1],
+                                                      int(size[0]), int(size[1]), _lib.stream_ptr()), "resize_bilinear_f32")
+    return out
 
 
 def batch_convert_for_resnet(batch_tensor: torch.Tensor) -> torch.Tensor:

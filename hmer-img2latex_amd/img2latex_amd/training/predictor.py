@@ -6,8 +6,11 @@ Checkpoint compatibility: ``from_checkpoint`` reads the dict th
 token table exactly as predictor.py:80-129 does.  The greedy loop of ``predict_batch``
 (predictor.py:283-358) runs as ONE persistent kernel launch (I2L_STOP_STICKY + argmax of softmax).
 
-Out of scope here (host-side preprocessing): image files / PIL images /
-resizing -- inputs are tensors already shaped (C,H,W) or (B,C,H,W) for the model.
+``predict`` / ``predict_batch`` take what the reference's take -- a path, a PIL image, a numpy array or a tensor
+-- through ``_prepare_image`` (predictor.py:396-462, incl. its hard-coded 64x800 target and its range-dependent
+normalisation of tensors); the pixels are resampled on the device (img2latex_amd.data).  ``predict_batch_ids`` /
+``evaluate_batch`` are this package's batch entry points for tensors ALREADY shaped for the model (the benchmark
+drivers: SURVEY 8b "feed tensors straight to the encoder").
 """
 from __future__ import annotations
 
@@ -68,6 +71,14 @@ def save_checkpoint(path: str, model: Seq2SeqModel, tokenizer: TokenTable, confi
                 "tokenizer_config": tokenizer.config()}, path)
 
 
+def _is_pil(obj) -> bool:
+    try:
+        from PIL import Image
+    except ImportError:                                                     # pragma: no cover
+        return False
+    return isinstance(obj, Image.Image)
+
+
 class Predictor:
     def __init__(self, model: Seq2SeqModel, tokenizer, device: Optional[torch.device] = None,
                  model_type: str = "cnn_lstm"):
@@ -90,7 +101,62 @@ class Predictor:
         return cls(model=model, tokenizer=tokenizer, device=device,
                    model_type=config.get("model", {}).get("name", "cnn_lstm"))
 
-    # ------------------------------------------------------------------
+    # ------------------------------------------------------------------ predictor.py:396-521
+    def _prepare_image(self, image) -> torch.Tensor:
+        """One image of any accepted type -> (1, C, 64, 800) on the device, with the reference's rules per type:
+        str -> load_image (aspect-preserving LANCZOS, pad / crop, [-1,1] or ImageNet statistics; a missing file gives
+        a zero image); tensor / ndarray -> bilinear resize when the size differs, ``/255*2-1`` iff min < 0 or max > 1
+        (:493-497 -- so a tensor already in [-1,1] is rescaled again, as in the reference); PIL image -> mode
+        conversion, Image.resize((800, 64)) with Pillow's default BICUBIC (aspect NOT kept), ``/255*2-1``."""
+        from ..data import load_image, preprocess_batch
+        img_size = (64, 800)                                                # :409-414, both model types
+        channels = 1 if self.model_type == "cnn_lstm" else 3
+        if isinstance(image, str):
+            t = load_image(image, img_size, channels).to(self.device)
+        elif isinstance(image, torch.Tensor):
+            t = self._preprocess_tensor(image, img_size, channels)
+        elif isinstance(image, np.ndarray):
+            t = self._preprocess_tensor(self._numpy_to_tensor(image, channels), img_size, channels)
+        elif _is_pil(image):
+            want = "L" if channels == 1 else "RGB"
+            if image.mode not in ("L", "RGB"):                              # decoding-side conversion stays with PIL
+                image = image.convert(want)
+            with torch.cuda.device(self.device):
+                t = preprocess_batch([np.array(image)], img_size, channels, "symmetric", keep_aspect=False,
+                                     resample="bicubic")[0]
+        else:
+            raise TypeError(f"Unsupported image type: {type(image)}. "
+                            "Expected str, torch.Tensor, numpy.ndarray, or PIL.Image.Image.")
+        if self.model_type == "resnet_lstm" and t.shape[0] == 1:            # :453-455
+            t = t.repeat(3, 1, 1)
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        return t
+
+    def _preprocess_tensor(self, tensor: torch.Tensor, img_size, channels: int) -> torch.Tensor:
+        """predictor.py:464-499 on the device."""
+        from ..data import resize_bilinear
+        tensor = tensor.to(self.device, dtype=torch.float32)
+        if tensor.dim() == 2:
+            tensor = tensor.unsqueeze(0)
+        if tuple(tensor.shape[-2:]) != tuple(img_size):
+            tensor = resize_bilinear(tensor.unsqueeze(0) if tensor.dim() == 3 else tensor, img_size)
+            if tensor.dim() == 4 and tensor.shape[0] == 1:
+                tensor = tensor.squeeze(0)
+        if bool(tensor.min() < 0) or bool(tensor.max() > 1):
+            tensor = tensor / 255.0
+            tensor = tensor * 2.0 - 1.0
+        return tensor
+
+    @staticmethod
+    def _numpy_to_tensor(array: np.ndarray, channels: int) -> torch.Tensor:
+        """predictor.py:501-521: (H,W) -> (1,H,W); (H,W,C) -> (C,H,W) unless the first axis already is 1 or 3."""
+        if array.ndim == 2:
+            array = np.expand_dims(array, axis=0)
+        elif array.ndim == 3 and array.shape[0] not in [1, 3]:
+            array = np.transpose(array, (2, 0, 1))
+        return torch.from_numpy(np.ascontiguousarray(array)).float()
+
     def _as_batch(self, images) -> torch.Tensor:
         if isinstance(images, torch.Tensor):
             t = images if images.dim() == 4 else images.unsqueeze(0)
@@ -189,12 +255,17 @@ class Predictor:
 
     def predict_batch(self, images, beam_size: int = 0, max_length: int = 141, temperature: float = 1.0,
                       top_k: int = 0, top_p: float = 0.0, batch_size: int = 16, seed: Optional[int] = None) -> List[str]:
-        """predictor.py:205-394.  As in the reference beam_size is clamped to 0 (:231-235)."""
-        x = self._as_batch(images)
+        """predictor.py:205-394: every image through ``_prepare_image`` (:242), stacked, the batched greedy loop.  As in
+        the reference beam_size is clamped to 0 (:231-235)."""
+        if isinstance(images, torch.Tensor):
+            images = [images] if images.dim() <= 3 else list(images)
         results: List[str] = []
         start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
-        for i in range(0, x.shape[0], batch_size):
-            for seq in self.predict_batch_ids(x[i:i + batch_size], max_length, temperature, top_k, top_p,
+        for i in range(0, len(images), batch_size):
+            x = torch.stack([self._prepare_image(im) for im in images[i:i + batch_size]])
+            if x.dim() == 5 and x.shape[1] == 1:                            # :254-257
+                x = x.squeeze(1)
+            for seq in self.predict_batch_ids(x, max_length, temperature, top_k, top_p,
                                               None if seed is None else seed + i):
                 if seq and seq[0] == start:                                 # :384-388
                     seq = seq[1:]
@@ -205,8 +276,9 @@ class Predictor:
 
     def predict(self, image, beam_size: int = 0, max_length: int = 141, temperature: float = 1.0, top_k: int = 0,
                 top_p: float = 0.0) -> str:
-        """predictor.py:139-203: one image through Seq2SeqModel.inference (greedy; beam clamped to 0)."""
-        x = self._as_batch(image)
+        """predictor.py:139-203: one image (path / PIL / ndarray / tensor) through ``_prepare_image`` and
+        Seq2SeqModel.inference (greedy; beam clamped to 0)."""
+        x = self._prepare_image(image).to(self.device)
         start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
         with torch.no_grad():
             seq = self.model.inference(image=x, start_token_id=start, end_token_id=end, max_length=max_length,

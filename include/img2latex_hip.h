@@ -360,6 +360,13 @@ int i2l_masked_accuracy(const float* logits, const int64_t* targets, int64_t row
  * fixed-point weights, ksize = i2l_lanczos_ksize(in_size, out_size). */
 int i2l_lanczos_ksize(int in_size, int out_size);
 int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out);
+/* The same tables for a named Pillow filter (values of PIL.Image.Resampling): LANCZOS is what load_image asks for
+ * (transforms.py:20-24), BICUBIC what Image.resize() defaults to -- the PIL.Image branch of Predictor._prepare_image
+ * (predictor.py:432-439) resizes straight to (800, 64) with it, aspect ratio NOT kept. */
+#define I2L_FILTER_LANCZOS 1
+#define I2L_FILTER_BICUBIC 3
+int i2l_resample_ksize(int filter, int in_size, int out_size);
+int i2l_resample_coeffs(int filter, int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out);
 
 /* One image of a ragged batch.  Offsets index `pixels` (bytes), `tables` (int32 elements) and the workspace
  * (bytes).  bv bounds must already be relative to the intermediate image when need_h (Resample.c: "Shift bounds
@@ -370,7 +377,7 @@ typedef struct i2l_resize_plan {
     int64_t bh_offset, kh_offset;  /* horizontal bounds / weights                                                    */
     int64_t bv_offset, kv_offset;  /* vertical bounds / weights                                                      */
     int32_t src_h, src_w, src_c;
-    int32_t new_w;                 /* int(round(out_h * src_w / src_h)), transforms.py:33-36                         */
+    int32_t new_w;                 /* int(round(out_h * src_w / src_h)), transforms.py:33-36; = out_w for a plain resize */
     int32_t ybox_first, tmp_rows;  /* source rows the vertical pass needs                                            */
     int32_t need_h, need_v;        /* new_w != src_w, out_h != src_h                                                 */
     int32_t kh_ksize, kv_ksize;
@@ -380,10 +387,18 @@ typedef struct i2l_resize_plan {
  * 1 channel; Pillow's integer colour 255 = (255,0,0) for 3 channels, as the reference executes) or centre-crop to
  * out_w -> /255 -> [-1,1] (1 channel) or ImageNet mean/std (3 channels) when `normalize`.  out (n, out_c, out_h,
  * out_w) fp32, bit-identical to the reference's tensor.  plans / tables live in device memory; max_tmp_px = the
- * largest tmp_rows*new_w over the batch (0 when no image needs a horizontal pass). */
+ * largest tmp_rows*new_w over the batch (0 when no image needs a horizontal pass).  normalize: 0 = /255 only,
+ * 1 = load_image's rule above, 2 = x * 2 - 1 on every channel (the PIL.Image branch of Predictor._prepare_image,
+ * predictor.py:447-451).  The filter is whatever the plan's tables were built with. */
 int i2l_preprocess_images(const uint8_t* pixels, const i2l_resize_plan* plans, const int32_t* tables, int n,
                           int max_tmp_px, int out_c, int out_h, int out_w, int normalize, void* workspace,
                           float* out, i2l_stream_t stream);
+
+/* The tensor branch of Predictor._prepare_image (predictor.py:483-491): torch.nn.functional.interpolate(mode=
+ * "bilinear", align_corners=False) of `planes` fp32 images (in_h, in_w) -> (out_h, out_w), contiguous; fp32 results
+ * within 1 ulp-level rounding of ATen's (tested <= 1e-6). */
+int i2l_resize_bilinear_f32(const float* in, float* out, int64_t planes, int in_h, int in_w, int out_h, int out_w,
+                            i2l_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -34,11 +34,27 @@ def _lanczos(x: float) -> float:
     return 0.0
 
 
-def precompute_coeffs(in_size: int, in0: float, in1: float, out_size: int):
+def _bicubic(x: float) -> float:
+    """Resample.c bicubic_filter (Keys, a = -0.5): Image.resize()'s default filter (predictor.py:439)."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+FILTERS = {"lanczos": (_lanczos, LANCZOS_SUPPORT), "bicubic": (_bicubic, 2.0)}
+
+
+def precompute_coeffs(in_size: int, in0: float, in1: float, out_size: int, flt: str = "lanczos"):
     """Resample.c precompute_coeffs + normalize_coeffs_8bpc: (ksize, bounds (out,2) int, kk (out,ksize) int32)."""
+    _filter, _support = FILTERS[flt]
     scale = float(np.float32(in1) - np.float32(in0)) / out_size
     filterscale = max(scale, 1.0)
-    support = LANCZOS_SUPPORT * filterscale
+    support = _support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), np.int32)
     kk = np.zeros((out_size, ksize), np.int32)
@@ -52,7 +68,7 @@ def precompute_coeffs(in_size: int, in0: float, in1: float, out_size: int):
         if xmax > in_size:
             xmax = in_size
         xmax -= xmin
-        k = [_lanczos((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        k = [_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
         ww = 0.0
         for w in k:
             ww += w
@@ -69,15 +85,16 @@ def _clip8(acc: np.ndarray) -> np.ndarray:
     return np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
 
 
-def resize_lanczos_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
-    """Image.resize((out_w, out_h), LANCZOS) for mode L (H,W) or RGB (H,W,3) uint8 (Image.py resize + Resample.c)."""
+def resize_lanczos_u8(img: np.ndarray, out_w: int, out_h: int, flt: str = "lanczos") -> np.ndarray:
+    """Image.resize((out_w, out_h), LANCZOS) for mode L (H,W) or RGB (H,W,3) uint8 (Image.py resize + Resample.c);
+    flt="bicubic" = Image.resize((out_w, out_h)) with no filter named."""
     h, w = img.shape[:2]
     if (w, h) == (out_w, out_h):
         return img.copy()
     src = img.reshape(h, w, -1).astype(np.int64)
     need_h, need_v = out_w != w, out_h != h
-    _, bh, kh = precompute_coeffs(w, 0.0, float(w), out_w)
-    _, bv, kv = precompute_coeffs(h, 0.0, float(h), out_h)
+    _, bh, kh = precompute_coeffs(w, 0.0, float(w), out_w, flt)
+    _, bv, kv = precompute_coeffs(h, 0.0, float(h), out_h, flt)
     ybox_first = int(bv[0, 0])
     ybox_last = int(bv[out_h - 1, 0] + bv[out_h - 1, 1])
     cur = src
@@ -148,3 +165,65 @@ def load_image_from_array(img: np.ndarray, img_size: Tuple[int, int], channels: 
             std = np.array([0.229, 0.224, 0.225], np.float32).reshape(-1, 1, 1)
             t = (t - mean) / std
     return t.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Predictor._prepare_image (img2latex/training/predictor.py:396-521): every input type -> (1, C, 64, 800)
+# ---------------------------------------------------------------------------------------------------------------
+def prepare_image(image, model_type: str = "cnn_lstm"):
+    """predictor.py:396-462.  str: load_image (:418-420; a missing / unreadable file -> zeros, utils.py:84-90);
+    tensor (:421-423) / ndarray (:424-427): _preprocess_tensor; PIL image (:428-451): convert, resize((800, 64)) with
+    Pillow's default BICUBIC, /255, *2-1 on every channel.  Returns a float32 torch tensor (1, C, 64, 800)."""
+    import torch
+    from PIL import Image
+    img_size, channels = (64, 800), (1 if model_type == "cnn_lstm" else 3)
+    if isinstance(image, str):
+        try:
+            pil = Image.open(image)
+            want = "L" if channels == 1 else "RGB"
+            arr = np.array(pil if pil.mode in ("L", "RGB") else pil.convert(want))
+            t = torch.from_numpy(load_image_from_array(arr, img_size, channels, True))
+        except Exception:
+            t = torch.zeros((channels, img_size[0], img_size[1]))
+    elif isinstance(image, torch.Tensor):
+        t = preprocess_tensor(image, img_size)
+    elif isinstance(image, np.ndarray):
+        t = preprocess_tensor(numpy_to_tensor(image), img_size)
+    elif isinstance(image, Image.Image):
+        want = "L" if channels == 1 else "RGB"
+        arr = np.array(image if image.mode in ("L", "RGB") else image.convert(want))
+        arr = resize_lanczos_u8(convert_mode(arr, channels), img_size[1], img_size[0], "bicubic")
+        arr = arr[None] if channels == 1 else np.transpose(arr, (2, 0, 1))
+        t = torch.from_numpy(arr.copy()).float() / 255.0
+        t = t * 2.0 - 1.0
+    else:
+        raise TypeError(f"Unsupported image type: {type(image)}")
+    if model_type == "resnet_lstm" and t.shape[0] == 1:
+        t = t.repeat(3, 1, 1)
+    return t.unsqueeze(0) if t.dim() == 3 else t
+
+
+def preprocess_tensor(tensor, img_size):
+    """predictor.py:464-499."""
+    import torch
+    if tensor.dim() == 2:
+        tensor = tensor.unsqueeze(0)
+    if tuple(tensor.shape[-2:]) != tuple(img_size):
+        tensor = torch.nn.functional.interpolate(tensor.unsqueeze(0) if tensor.dim() == 3 else tensor, size=img_size,
+                                                 mode="bilinear", align_corners=False)
+        if tensor.dim() == 4 and tensor.shape[0] == 1:
+            tensor = tensor.squeeze(0)
+    if tensor.min() < 0 or tensor.max() > 1:
+        tensor = tensor / 255.0
+        tensor = tensor * 2.0 - 1.0
+    return tensor
+
+
+def numpy_to_tensor(array: np.ndarray):
+    """predictor.py:501-521."""
+    import torch
+    if array.ndim == 2:
+        array = np.expand_dims(array, axis=0)
+    elif array.ndim == 3 and array.shape[0] not in [1, 3]:
+        array = np.transpose(array, (2, 0, 1))
+    return torch.from_numpy(array).float()

@@ -1,0 +1,147 @@
+"""`predict CHECKPOINT IMAGE` end to end (cli.py:253-308 -> Predictor.from_checkpoint -> Predictor.predict ->
+_prepare_image -> load_image -> encoder -> greedy search -> tokenizer.decode) against what the REFERENCE produced from
+the same checkpoint file and the same PNG (tests/golden/make_golden_predict.py), for every input type
+`_prepare_image` accepts (predictor.py:396-521): path, PIL image, numpy arrays, tensors.
+
+CPU: the oracle restatement of `_prepare_image` against the reference's prepared tensors (pins the BICUBIC tables
+and the branch logic), the host coefficient helper, the CLI's argument surface.  GPU: the drop-in Predictor and
+`python -m img2latex_amd predict` themselves."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import preprocess_oracle as PO
+from helpers import GOLDEN
+from img2latex_amd import _lib, synth
+
+sys.path.insert(0, GOLDEN)
+PT = os.path.join(GOLDEN, "predict_64x800.pt")
+PNG = os.path.join(GOLDEN, "predict_page.png")
+PNG_RGB = os.path.join(GOLDEN, "predict_page_rgb.png")
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _cases():
+    """The objects make_golden_predict.py handed to the reference (tests/golden/predict_inputs.py)."""
+    from predict_inputs import inputs
+    cases = {"path_gray_png": PNG, "path_rgb_png": PNG_RGB, "path_missing": os.path.join(GOLDEN, "no_such_file.png")}
+    cases.update(inputs())
+    return cases
+
+
+def _fixture():
+    d = np.load(os.path.join(GOLDEN, "predict_64x800.npz"))
+    return d, json.loads(str(d["names"])), json.loads(str(d["texts"]))
+
+
+def test_oracle_prepare_image_vs_reference():
+    d, names, _ = _fixture()
+    cases = _cases()
+    assert list(cases) == names
+    for name in names:
+        got = PO.prepare_image(cases[name], "cnn_lstm")
+        assert tuple(got.shape) == (1, 1, 64, 800)
+        flat = got.reshape(-1).numpy()
+        exact = name.startswith(("path_", "pil_")) or name == "tensor_sized_01"      # integer resampling: bit-exact
+        if exact:
+            assert np.array_equal(flat[::97], d[f"prep_{name}_sample"]), name
+            assert synth.checksum(flat) == float(d[f"prep_{name}_checksum"]), name
+        else:
+            assert np.abs(flat[::97] - d[f"prep_{name}_sample"]).max() <= 1e-6, name
+
+
+def test_bicubic_coefficients_equal_oracle():
+    L = _lib.lib()
+    for (a, b) in [(300, 800), (700, 800), (40, 64), (90, 64), (800, 800), (64, 64), (1200, 800), (17, 64)]:
+        ks, bo, ko = PO.precompute_coeffs(a, 0.0, float(a), b, "bicubic")
+        assert L.i2l_resample_ksize(_lib.FILTER_BICUBIC, a, b) == ks
+        bounds, kk = np.zeros((b, 2), np.int32), np.zeros((b, ks), np.int32)
+        assert L.i2l_resample_coeffs(_lib.FILTER_BICUBIC, a, b, bounds.ctypes.data, kk.ctypes.data) == 0
+        assert np.array_equal(bounds, bo) and np.array_equal(kk, ko), (a, b)
+    assert L.i2l_resample_ksize(7, 10, 10) == 0 and L.i2l_resample_coeffs(7, 10, 10, bounds.ctypes.data, kk.ctypes.data) < 0
+
+
+def test_cli_surface_matches_the_reference():
+    """Option names of cli.py:104-120 / :253-269; --device cpu is refused, not silently accepted."""
+    from img2latex_amd import cli
+    for argv in (["predict", "--help"], ["train", "--help"]):
+        with pytest.raises(SystemExit) as e:
+            cli.main(argv)
+        assert e.value.code == 0
+    r = subprocess.run([sys.executable, "-m", "img2latex_amd", "predict", "--help"], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=os.path.join(REPO, "hmer-img2latex_amd")))
+    assert r.returncode == 0
+    for opt in ("checkpoint_path", "image_path", "--beam-size", "--max-length", "--temperature", "--top-k", "--top-p", "--device"):
+        assert opt in r.stdout, opt
+    r = subprocess.run([sys.executable, "-m", "img2latex_amd", "train", "--help"], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=os.path.join(REPO, "hmer-img2latex_amd")))
+    for opt in ("--config-path", "--experiment-name", "--checkpoint-path", "--data-dir", "--device", "--seed"):
+        assert opt in r.stdout, opt
+    with pytest.raises(SystemExit):
+        cli.predict(PT, PNG, device="cpu")
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_prepare_image_on_device_vs_reference():
+    from img2latex_amd.training import Predictor
+    d, names, _ = _fixture()
+    pred = Predictor.from_checkpoint(PT, device=torch.device("cuda"))
+    cases = _cases()
+    for name in names:
+        got = pred._prepare_image(cases[name])
+        assert got.is_cuda and tuple(got.shape) == (1, 1, 64, 800), name
+        flat = got.reshape(-1).cpu().numpy()
+        if name.startswith(("path_", "pil_")) or name == "tensor_sized_01":
+            assert np.array_equal(flat[::97], d[f"prep_{name}_sample"]), name
+            assert synth.checksum(flat) == float(d[f"prep_{name}_checksum"]), name
+        else:                                                       # fp32 bilinear: rounding-level differences
+            assert np.abs(flat[::97] - d[f"prep_{name}_sample"]).max() <= 1e-6, name
+    with pytest.raises(TypeError):
+        pred._prepare_image(3.5)
+
+
+@pytest.mark.gpu
+def test_predict_strings_vs_reference():
+    from img2latex_amd.training import Predictor
+    d, names, texts = _fixture()
+    pred = Predictor.from_checkpoint(PT, device=torch.device("cuda"))
+    cases = _cases()
+    for name in names:
+        assert pred.predict(cases[name], max_length=40) == texts[name], name
+        assert pred.predict(cases[name], max_length=25, temperature=0.7) == texts[name + "@T0.7"], name
+    order = json.loads(str(d["batch_order"]))
+    assert pred.predict_batch([cases[n] for n in order], max_length=40, batch_size=3) == texts["predict_batch"]
+    assert pred.predict(PNG, beam_size=5, max_length=40) == texts["path_gray_png"]         # clamped to greedy (:161-166)
+
+
+@pytest.mark.gpu
+def test_cli_predict_and_train(tmp_path):
+    """`python -m img2latex_amd predict CHECKPOINT IMAGE --max-length 40` prints the reference's string;
+    `train --config-path ... --checkpoint-path ... --synthetic-steps 3` resumes from the reference-written checkpoint,
+    steps, and writes a checkpoint the predictor loads again."""
+    import yaml
+    _, _, texts = _fixture()
+    env = dict(os.environ, PYTHONPATH=os.path.join(REPO, "hmer-img2latex_amd"))
+    r = subprocess.run([sys.executable, "-m", "img2latex_amd", "predict", PT, PNG, "--max-length", "40", "--device", "cuda"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == texts["path_gray_png"]
+    ck = torch.load(PT, map_location="cpu", weights_only=False)
+    config = dict(ck["config"])
+    config["data"] = {"batch_size": 8, "max_seq_length": 20}
+    config["training"] = dict(config["training"], device="cuda", epochs=1)
+    cfg_path = tmp_path / "config.yaml"
+    cfg_path.write_text(yaml.safe_dump(config))
+    from img2latex_amd import cli
+    out = cli.train(str(cfg_path), "cli_test", PT, None, "cuda", 7, synthetic_steps=3, output_dir=str(tmp_path / "outputs"))
+    assert out["steps"] == 3 and np.isfinite(out["loss"]) and os.path.exists(out["checkpoint"])
+    again = torch.load(out["checkpoint"], map_location="cpu", weights_only=False)
+    assert set(again) == set(ck) and again["optimizer_state_dict"]["state"][0]["step"].item() == 3.0
+    assert isinstance(cli.predict(out["checkpoint"], PNG, max_length=10), str)
+    assert cli.main(["train", "--config-path", str(tmp_path / "missing.yaml"), "--synthetic-steps", "1"]) == 1   # cli.py:247-250
