@@ -63,7 +63,7 @@ struct BeamGroupParams {
     double* score_out;
     u64_t* xchg;          // [n_groups][2][4][BG_GRAN]
     unsigned* status;
-    int agent_scope;      // != 0: every exchange store at agent scope (I2L_FLAG_AGENT_SCOPE_EXCHANGE)
+    GroupOpts opts;       // poll limits, exchange flavour (group_common.inc.h)
 };
 
 // all-reduce over the 64 lanes of a wave: 4 rotate steps inside each row of 16, then the 4 row results
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups) return;
+    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
     const int T = p.T, V = w.V;
     const int img0 = group * IPG;
     const int ul = tid >> 3, ke = tid & 7;
@@ -188,14 +188,14 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
             if ((++spins & 255u) == 0) {
                 const long long now = (long long)wall_clock64();
                 if (t_start == 0) t_start = now;
-                else if (now - t_start > GRP_TIMEOUT_TICKS) { bad = true; break; }
+                else if (now - t_start > p.opts.limit_first) { bad = true; break; }
             }
         }
         const bool all_same = __all(lane >= 3 || (unsigned)pv == xcc);
         if (lane == 0) { flg[1] = (all_same && !bad) ? 1 : 0; if (bad) flg[0] = 1; }
     }
     __syncthreads();
-    const bool local = flg[1] != 0 && !p.agent_scope;
+    const bool local = flg[1] != 0 && !p.opts.agent_scope;
 
     float c_new[BG_NP];
 #pragma unroll
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
                     if ((++spins & 255u) == 0) {
                         const long long now = (long long)wall_clock64();
                         if (t_start == 0) t_start = now;
-                        else if (now - t_start > GRP_TIMEOUT_TICKS) { bad = true; break; }
+                        else if (now - t_start > p.opts.limit_step) { bad = true; break; }
                     }
                     if (b_act) {
                         gv = load_granule(b_src + slot * BG_CW);
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(GNT) void beam_group_kernel(BeamGroupParams p) {
                 if ((++spins & 255u) == 0) {
                     const long long now = (long long)wall_clock64();
                     if (t_start == 0) t_start = now;
-                    else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
+                    else if (now - t_start > p.opts.limit_step) { failed = true; break; }
                 }
             }
             I2L_STAMP(4);

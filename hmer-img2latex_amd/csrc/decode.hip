@@ -1056,7 +1056,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
         char* xb = const_cast<char*>(base) + lo.xchg;           // scratch region of the workspace
         gp.status = reinterpret_cast<unsigned*>(xb);
         gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
-        gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
+        gp.opts = group_opts(steps, flags);
         hipStream_t gs = i2l_s(stream);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP_LDS) == hipSuccess) {
@@ -1183,7 +1183,7 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
         const size_t xbytes = GROUP_STATUS_BYTES + (size_t)i2l_cdiv(gp.n_groups, 8) * 8 * BEAM_XCHG_PER_GROUP;
         gp.status = reinterpret_cast<unsigned*>(xb);
         gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
-        gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
+        gp.opts = group_opts(steps, flags);
         if (hipMemsetAsync(xb, 0, xbytes, s) != hipSuccess) return I2L_ERR_LAUNCH;
         switch (beam) {
             case 2: return launch_beam_group<2>(gp, s);
@@ -1213,6 +1213,11 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
         case 8: return launch_beam<8>(p, lds, s);
         default: return I2L_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" size_t i2l_decoder_group_status_offset(int rows, int vocab, int embed, int hidden, int layers) {
+    const Layout lo = make_layout(rows, vocab, embed, hidden, layers);
+    return lo.xchg_bytes ? lo.xchg : 0;
 }
 
 #ifdef I2L_GROUP_STAMPS

@@ -65,7 +65,7 @@ struct GroupParams {
     int use_temp, stop, end_id;
     u64_t* xchg;          // [n_groups][2][GQ][GRAN]
     unsigned* status;     // [0] != 0: a poll timed out
-    int agent_scope;      // != 0: every exchange store at agent scope (I2L_FLAG_AGENT_SCOPE_EXCHANGE)
+    GroupOpts opts;       // poll limits, exchange flavour (group_common.inc.h)
 };
 
 constexpr int DPP_SHL12 = 0x10C;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups) return;
+    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
     const int B = p.B, T = p.T, V = w.V;
     const int row0 = group * GQ;
     // gates: hidden unit 64m + ul, k = ke (mod 8) -> 32 k, 4 gates x 4 rows;  cell: lanes ke < 4 own (unit, row ke)
@@ -141,14 +141,21 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
             if ((++spins & 255u) == 0) {
                 const long long now = (long long)wall_clock64();
                 if (t_start == 0) t_start = now;
-                else if (now - t_start > GRP_TIMEOUT_TICKS) { bad = true; break; }
+                else if (now - t_start > p.opts.limit_first) { bad = true; break; }
             }
         }
         const bool all_same = __all(lane >= 3 || (unsigned)pv == xcc);
-        if (lane == 0) { cnt_s[3] = (all_same && !bad) ? 1 : 0; if (bad) cnt_s[2] = 1; }
+        if (lane == 0) {
+            cnt_s[3] = (all_same && !bad) ? 1 : 0;
+            if (bad) cnt_s[2] = 1;
+            if (m == 0 && !bad) {                            // placement statistics of the launch (read by the host on request)
+                atomicAdd(p.status + GRP_STAT_GROUPS, 1u);
+                if (all_same && !p.opts.agent_scope) atomicAdd(p.status + GRP_STAT_LOCAL, 1u);
+            }
+        }
     }
     __syncthreads();
-    const bool local = cnt_s[3] != 0 && !p.agent_scope;
+    const bool local = cnt_s[3] != 0 && !p.opts.agent_scope;
 
     // token of the row this lane's cell belongs to (row ke & 3) and its table row, gathered as early as the token is known
     const int my_r = ke & 3;
@@ -226,7 +233,10 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
             }
         }
         I2L_STAMP(0);
-        // ---- B. wait for the tokens if they are not there yet
+        // ---- B. wait for the tokens if they are not there yet.  A wave whose poll times out does NOT leave on its own:
+        //         it raises cnt_s[2], skips the rest of the step's work and meets the others at the step's barrier, after
+        //         which every wave leaves together (uniform barrier use on the failure path too)
+        bool bail = false;
         if (!have) {
             long long t_start = 0;
             unsigned spins = 0;
@@ -238,12 +248,12 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
                 if ((++spins & 255u) == 0) {
                     const long long now = (long long)wall_clock64();
                     if (t_start == 0) t_start = now;
-                    else if (now - t_start > GRP_TIMEOUT_TICKS) { failed = true; break; }
+                    else if (now - t_start > p.opts.limit_step) { bail = true; break; }
                 }
             }
-            if (failed) { cnt_s[2] = 1; break; }
+            if (bail) cnt_s[2] = 1;
         }
-        if (t > 0) {
+        if (t > 0 && !bail) {
             const int tk[4] = {tk0, tk1, tk2, tk3};
             bool all_fin = true;
 #pragma unroll
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
         const int par = t & 1;
         u64_t* slot = xg + (size_t)par * GQ * GRAN;
         float* hcur = h_s + par * 1024;
-        {
+        if (!bail) {
             const float4 genc = genc_s[tid];
             const bool b0 = ke & 1, b1 = ke & 2, b2 = ke & 4;
             float z[2];                                     // lanes ke < 4: gates (i, f); ke >= 4: (g, o); row ke & 3
@@ -283,13 +293,13 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
             c_own = fg * c_own + ig * gg;
             h_own = og * tanhf_(c_own);
         }
-        if (ke < 4) {
+        if (ke < 4 && !bail) {
             store_granule(slot + (size_t)m * GRAN + ul * 4 + ke, granule(epoch, h_own), local);
             hcur[m * 256 + ul * 4 + ke] = h_own;
         }
         I2L_STAMP(2);
         // ---- D. the other three quarters of h: threads 0..255 fetch peers 0 and 1, threads 256..511 peer 2
-        {
+        if (!bail) {
             u64_t gr[2];
             const int gi = tid & 255;
             const int qa = tid < 256 ? 0 : 2;
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
                 if ((++spins & 255u) == 0) {
                     const long long now = (long long)wall_clock64();
                     if (t_start == 0) t_start = now;
-                    else if (now - t_start > GRP_TIMEOUT_TICKS) { cnt_s[2] = 1; break; }
+                    else if (now - t_start > p.opts.limit_step) { cnt_s[2] = 1; break; }
                 }
             }
             I2L_STAMP(3);

@@ -7,6 +7,31 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr long long GRP_TIMEOUT_TICKS = 300000000ll;   // 3 s of the 100 MHz wall clock
 
+// Per-launch options of a grouped kernel.  A group only makes progress while its four workgroups are resident
+// together; the launch is not cooperative, so every poll has a wall-clock limit.  Two limits: the FIRST poll of a
+// workgroup (the placement exchange: "are my three peers there at all?") gets a short one -- 10 ms plus what earlier
+// groups of the same launch may legitimately hold the CUs for (50 us per step) -- so that on a GPU shared with other
+// work the launch gives up in milliseconds and the host falls back to the row-per-workgroup kernel; every later poll
+// (peers known to be resident) keeps the 3 s limit.  drop_member is a TEST hook (I2L_FLAG_TEST_DROP_MEMBER): member 3
+// of every group exits at once, which forces the time-out path end to end.
+struct GroupOpts {
+    long long limit_first, limit_step;
+    int agent_scope;      // != 0: every exchange store at agent scope (I2L_FLAG_AGENT_SCOPE_EXCHANGE)
+    int drop_member;
+};
+inline GroupOpts group_opts(int steps, int flags) {
+    GroupOpts o;
+    o.limit_first = 1000000ll + 5000ll * (long long)steps;
+    o.limit_step = GRP_TIMEOUT_TICKS;
+    if (flags & I2L_FLAG_TEST_SHORT_TIMEOUT) o.limit_first = o.limit_step = 200000ll;      // 2 ms
+    o.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
+    o.drop_member = (flags & I2L_FLAG_TEST_DROP_MEMBER) ? 1 : 0;
+    return o;
+}
+// status block of a grouped launch (zeroed by the launch's memset node): [0] != 0 a poll timed out, [1] groups that
+// went through the placement exchange, [2] of those, groups whose four members measured ONE XCD (L2-local stores)
+constexpr int GRP_STAT_FAILED = 0, GRP_STAT_GROUPS = 1, GRP_STAT_LOCAL = 2;
+
 
 // local == false: sc1 store (write-through to memory, seen from every XCD).  local == true (all four members were
 // found on ONE XCD): sc0 store, the line stays in that XCD's L2 where the peers' sc1 loads (L1 bypassed) find it --

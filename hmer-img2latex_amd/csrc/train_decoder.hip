@@ -718,7 +718,7 @@ extern "C" int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* 
             gp.ACT = p.ACT[0]; gp.C = p.C[0]; gp.Hout = p.Hout[0]; gp.Hprev = p.Hprev[0];
             gp.status = reinterpret_cast<unsigned*>(base + lo.xchg);
             gp.xchg = reinterpret_cast<u64_t*>(base + lo.xchg + 2048);
-            gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
+            gp.opts = group_opts(T, flags);
             const size_t used = 2048 + (size_t)i2l_cdiv(lo.n_groups, 8) * 8 * 2 * 4 *
                                        (B <= 64 ? TGF1_GRAN : (B <= 128 ? TGF2_GRAN : TGF_GRAN)) * sizeof(u64_t);
             if (hipMemsetAsync(base + lo.xchg, 0, used, s) != hipSuccess) return I2L_ERR_LAUNCH;
@@ -854,7 +854,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
             gp.Whh = p.Whh[0]; gp.DG = p.DG[0];
             gp.status = reinterpret_cast<unsigned*>(base + lo.xchg);
             gp.xchg = reinterpret_cast<u64_t*>(base + lo.xchg + 2048);
-            gp.agent_scope = (flags & I2L_FLAG_AGENT_SCOPE_EXCHANGE) ? 1 : 0;
+            gp.opts = group_opts(T, flags);
             if (hipMemsetAsync(base + lo.xchg, 0, lo.xchg_bytes, s) != hipSuccess) return I2L_ERR_LAUNCH;
             if (B <= 64)
                 hipLaunchKernelGGL(lstm_train_bwd_group1_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(TGT), 0, s, gp);

@@ -23,6 +23,7 @@ MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
 # kernel-selection flags (include/img2latex_hip.h I2L_FLAG_*): explicit arguments, the library reads no environment
 FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0x1, 0x2, 0x4, 0x8
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
+FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks of the grouped kernels
 
 
 def flag_resnet_ring_depth(n: int) -> int:
@@ -105,6 +106,7 @@ _SIGNATURES.update({
     "i2l_lanczos_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "i2l_preprocess_images": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p]),
+    "i2l_decoder_group_status_offset": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "i2l_resample_ksize": (c_int, [c_int, c_int, c_int]),
     "i2l_resample_coeffs": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "i2l_resize_bilinear_f32": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p]),

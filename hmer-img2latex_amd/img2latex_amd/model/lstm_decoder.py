@@ -137,6 +137,19 @@ class LSTMDecoder(nn.Module):
         _lib.mark("prepare")
         return w, keep, enc
 
+    def group_status(self):
+        """Diagnostics of the LAST grouped greedy launch on the current stream (synchronises): {"timed_out", "groups",
+        "groups_on_one_xcd"} -- how many 4-workgroup groups ran and how many of them found their members on one XCD
+        and exchanged through its L2 -- or None when these dimensions / this batch have no grouped path."""
+        if self._ws is None or self._ws_key is None:
+            return None
+        off = _lib.lib().i2l_decoder_group_status_offset(self._ws_key[0], self.vocab_size, self.embedding_dim,
+                                                         self.hidden_dim, self.lstm_layers)
+        if off == 0:
+            return None
+        st = self._ws[off:off + 16].view(torch.int32).cpu().tolist()
+        return {"timed_out": bool(st[0]), "groups": st[1], "groups_on_one_xcd": st[2]}
+
     def run_steps(self, encoder_output: torch.Tensor, steps: int, tok0: torch.Tensor,
                   forced: Optional[torch.Tensor] = None, hidden: Optional[Hidden] = None,
                   temperature: float = 1.0, select: int = _lib.SELECT_LOGITS, stop: int = _lib.STOP_NONE,

@@ -54,6 +54,10 @@ typedef void* i2l_stream_t;
                                           agent scope (sc1, write-through) -- the HSA-memory-model-conformant flavour --
                                           even when the group's members share an XCD and the faster L2-local
                                           (workgroup-scope) stores would be used; same results, ~0.8 us per step slower */
+#define I2L_FLAG_TEST_SHORT_TIMEOUT 0x40 /* grouped kernels, TEST hook: every poll limit 2 ms instead of (10 ms + 50 us per
+                                          step) for a workgroup's first poll and 3 s for the later ones               */
+#define I2L_FLAG_TEST_DROP_MEMBER 0x80 /* grouped kernels, TEST hook: member 3 of every group exits at once, so its peers
+                                          time out: exercises the failure path (ids -3 / len -3 / NaN, host fallback)  */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
 
 int i2l_version(void);
@@ -349,6 +353,12 @@ int i2l_compact_ids(const int32_t* ids, int rows, int width, int stride, int end
  * ties.  The (B,T,V) logits never leave the device (the reference copies them to the host every step). */
 int i2l_masked_accuracy(const float* logits, const int64_t* targets, int64_t rows, int vocab, int64_t pad_id,
                         uint64_t* correct_total_out, i2l_stream_t stream);
+
+/* Where the grouped greedy kernel's status words live inside the decoder workspace (0: these dimensions have no
+ * grouped path): uint32 [0] != 0 -> a poll timed out (the ids are -3), [1] groups that completed the placement
+ * exchange in the last launch, [2] of those, the groups whose four workgroups measured themselves on ONE XCD and
+ * therefore exchanged through that XCD's L2 (the fast flavour).  Diagnostics: read after synchronising the stream. */
+size_t i2l_decoder_group_status_offset(int rows, int vocab, int embed, int hidden, int layers);
 
 /* ------------------------------------------------------------------------
  * Image preprocessing (reference img2latex/data/utils.py:18-90, data/transforms.py:26-56), SURVEY section 8(f)-3

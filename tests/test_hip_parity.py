@@ -874,3 +874,58 @@ def test_agent_scope_exchange_gives_identical_results():
         outs.append(ts.flat_params.clone())
     # (the embedding-gradient scatter adds with atomics, so two runs of the SAME kernels agree to rounding, not to the bit)
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-6
+
+
+def test_grouped_kernels_forced_timeout_fails_loudly_and_falls_back():
+    """The failure path of the grouped kernels, forced: I2L_FLAG_TEST_DROP_MEMBER makes member 3 of every group exit at
+    once, so the three others never see its placement granule; with I2L_FLAG_TEST_SHORT_TIMEOUT their polls give up
+    after 2 ms (production: 10 ms + 50 us per step for a workgroup's first poll, 3 s afterwards).  Required: the launch
+    RETURNS (no hang), greedy ids are -3 on every row and the logits NaN, beam lengths -3 -> the host entry points warn
+    and produce the reference's result on the row-per-workgroup kernels; a training step's gradients are NaN and the
+    fused clip + Adam skips the update."""
+    import time
+    from img2latex_amd.training import TrainStep
+    d, cfg, sd_kw = load("primary_cfg2_clock")
+    m, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    x = torch.from_numpy(synth.make_images(64, cfg, seed=1234)).to(DEV)
+    bad = _lib.FLAG_TEST_DROP_MEMBER | _lib.FLAG_TEST_SHORT_TIMEOUT
+    with torch.no_grad():
+        enc = m.encoder(x)
+        good, _ = m.greedy_ids(enc, START, END, 60)
+        st = m.decoder.group_status()
+        assert st == {"timed_out": False, "groups": 16, "groups_on_one_xcd": st["groups_on_one_xcd"]}
+        record("grouped greedy decode, 16 groups: groups whose members share one XCD", st["groups_on_one_xcd"])
+        tok0 = torch.full((64,), START, dtype=torch.int32, device=DEV)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids, logits, _ = m.decoder.run_steps(enc, 60, tok0, want_logits=True, flags=bad)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 1.0                                  # milliseconds, not the 3 s limit
+        assert bool((ids == -3).all()) and bool(torch.isnan(logits[:, :, 0]).all())
+        assert m.decoder.group_status()["timed_out"]
+        with pytest.raises(RuntimeError):
+            _lib.check_ids(ids.cpu())
+        m.decoder.kernel_flags = bad
+        try:
+            with pytest.warns(RuntimeWarning):
+                via_host = m.greedy_ids_host(enc, START, END, 60)              # falls back to the row-per-workgroup kernel
+            with pytest.warns(UserWarning):
+                beams = m.beam_search_batch(enc[:10].contiguous(), START, END, 40, 5)
+        finally:
+            m.decoder.kernel_flags = 0
+        assert torch.equal(via_host, good.cpu())
+        assert beams == m.beam_search_batch(enc[:10].contiguous(), START, END, 40, 5)
+    cfg3 = synth.model_config(dropout=0.0)
+    mm = Seq2SeqModel("cnn_lstm", cfg3["vocab_size"], synth.encoder_params(cfg3), synth.decoder_params(cfg3))
+    mm.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(cfg3, seed=42).items()})
+    mm = mm.to(DEV)
+    ts = TrainStep(mm)
+    before = ts.flat_params.clone()
+    xs = torch.from_numpy(synth.make_images(8, cfg3, seed=5)).to(DEV)
+    forms = torch.from_numpy(synth.make_formulas(8, 40, cfg3["vocab_size"], seed=6)).to(DEV)
+    mm.decoder.kernel_flags = bad
+    out = ts.step(xs, forms)
+    assert float(out["skipped"]) == 1.0 and torch.equal(ts.flat_params, before)
+    mm.decoder.kernel_flags = 0
+    out = ts.step(xs, forms)
+    assert float(out["skipped"]) == 0.0 and np.isfinite(float(out["loss"]))
