@@ -270,6 +270,9 @@ def main():
                         us_per_decode_step=round(dom["ms"] * 1e3 / executed_steps_holder[0], 3),
                         note="per-step latency chain (two in-group L2 exchanges + LSTM cell), not arithmetic: "
                              "frac = algorithmic 1.835 MFLOP/token, frac_executed = the 0.786 MFLOP/token the kernel runs")
+        gst = model.decoder.group_status()
+        if gst is not None:     # measured placement of the last launch: L2-local exchange needs a group's 4 workgroups on one XCD
+            roofline["groups_on_one_xcd"] = f"{gst['groups_on_one_xcd']}/{gst['groups']}"
     else:
         roofline.update(bound="mfma")
     enc_stages = [st for st in stages if st["kernel"].startswith("conv") or st["kernel"] == "fc"]

@@ -34,13 +34,13 @@ struct TrainGroupBwd {
 
 // Are the four members on one XCD?  (decode_group.inc.h: measured, never assumed.)  Returns via LDS word flag[1];
 // flag[0] is set when the wait itself timed out.  Called by every thread; contains a barrier.
-__device__ __forceinline__ bool group_placement_local(u64_t* xg, int gran, int xslot, int m, int* flag, long long limit) {
+__device__ __forceinline__ bool group_placement_local(u64_t* xg, int gran, int xslot, int m, int* flag, long long limit, bool silent) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 0xFu;
-        if (lane == 0) store_granule(xg + (size_t)m * gran + xslot, granule(0xC0DEu, __uint_as_float(xcc)), false);
+        if (lane == 0 && !silent) store_granule(xg + (size_t)m * gran + xslot, granule(0xC0DEu, __uint_as_float(xcc)), false);
         const int pq = (lane & 3) + ((lane & 3) >= m ? 1 : 0);
         u64_t pv = 0;
         bool bad = false;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group_kernel(TrainGroupFwd
     const int tid = threadIdx.x;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
+    if (group >= p.n_groups) return;
     const int B = p.B, T = p.T;
     const int row0 = group * 4;
     const int ul = tid >> 3, ke = tid & 7, kr = ke & 3;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group_kernel(TrainGroupFwd
     }
     for (int idx = tid; idx < 2 * 1024; idx += TGT) (&h_s[0][0])[idx] = 0.f;
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGF_GRAN;
-    const bool local = group_placement_local(xg, TGF_GRAN, 272, m, flag, p.opts.limit_first) && !p.opts.agent_scope;      // barrier inside: h_s zeroed
+    const bool local = group_placement_local(xg, TGF_GRAN, 272, m, flag, p.opts.limit_first, p.opts.drop_member && m == 3) && !p.opts.agent_scope;      // barrier inside: h_s zeroed
     const int row = min(row0 + kr, B - 1);
     const bool live = ke < 4 && row0 + kr < B;                                  // this lane owns (unit, row kr)
     float c_own = 0.f, h_own = 0.f;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group_kernel(TrainGroupBwd
     const int tid = threadIdx.x, lane = tid & 63;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
+    if (group >= p.n_groups) return;
     const int B = p.B, T = p.T;
     const int row0 = group * 4;
     constexpr int G = 1024, H = 256;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group_kernel(TrainGroupBwd
     const int row = min(row0 + o_row, B - 1);
     const bool owner = ns < 16, live = owner && row0 + o_row < B;
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGB_GRAN;
-    const bool local = group_placement_local(xg, TGB_GRAN, 1024, m, flag, p.opts.limit_first) && !p.opts.agent_scope;
+    const bool local = group_placement_local(xg, TGB_GRAN, 1024, m, flag, p.opts.limit_first, p.opts.drop_member && m == 3) && !p.opts.agent_scope;
     float dh_rec = 0.f, dc_next = 0.f;
     bool failed = false;
     float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f);                             // step t-1's reads, requested during step t
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group2_kernel(TrainGroupFw
     const int tid = threadIdx.x;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
+    if (group >= p.n_groups) return;
     const int B = p.B, T = p.T;
     const int row0 = group * 2;
     const int ul = tid >> 3, ke = tid & 7, kr = ke & 1;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group2_kernel(TrainGroupFw
     }
     for (int idx = tid; idx < 2 * 512; idx += TGT) (&h_s[0][0])[idx] = 0.f;
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGF2_GRAN;
-    const bool local = group_placement_local(xg, TGF2_GRAN, 144, m, flag, p.opts.limit_first) && !p.opts.agent_scope;   // barrier inside: h_s zeroed
+    const bool local = group_placement_local(xg, TGF2_GRAN, 144, m, flag, p.opts.limit_first, p.opts.drop_member && m == 3) && !p.opts.agent_scope;   // barrier inside: h_s zeroed
     const int row = min(row0 + kr, B - 1);
     const bool live = ke < 2 && row0 + kr < B;                                  // this lane owns (unit, row kr)
     float c_own = 0.f, h_own = 0.f;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group2_kernel(TrainGroupBw
     const int tid = threadIdx.x;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
+    if (group >= p.n_groups) return;
     const int B = p.B, T = p.T;
     const int row0 = group * 2;
     constexpr int G = 1024, H = 256;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group2_kernel(TrainGroupBw
     const int row = min(row0 + o_row, B - 1);
     const bool owner = ns < 8, live = owner && row0 + o_row < B;
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGB2_GRAN;
-    const bool local = group_placement_local(xg, TGB2_GRAN, 512, m, flag, p.opts.limit_first) && !p.opts.agent_scope;
+    const bool local = group_placement_local(xg, TGB2_GRAN, 512, m, flag, p.opts.limit_first, p.opts.drop_member && m == 3) && !p.opts.agent_scope;
     float dh_rec = 0.f, dc_next = 0.f;
     bool failed = false;
     float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f);                             // step t-1's reads, requested during step t
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group1_kernel(TrainGroupFw
     const int tid = threadIdx.x;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
+    if (group >= p.n_groups) return;
     const int T = p.T;
     const int row = group;                                 // n_groups == B
     const int ul = tid >> 3, ke = tid & 7;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_fwd_group1_kernel(TrainGroupFw
     }
     for (int idx = tid; idx < 2 * 256; idx += TGT) (&h_s[0][0])[idx] = 0.f;
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGF1_GRAN;
-    const bool local = group_placement_local(xg, TGF1_GRAN, 80, m, flag, p.opts.limit_first) && !p.opts.agent_scope;   // barrier inside: h_s zeroed
+    const bool local = group_placement_local(xg, TGF1_GRAN, 80, m, flag, p.opts.limit_first, p.opts.drop_member && m == 3) && !p.opts.agent_scope;   // barrier inside: h_s zeroed
     const bool live = ke == 0;                                                  // this lane owns the cell of `unit`
     auto hpos = [](int k) { return (((k >> 4) * 8 + (k & 7)) << 1) + ((k >> 3) & 1); };
     float c_own = 0.f, h_own = 0.f;
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group1_kernel(TrainGroupBw
     const int tid = threadIdx.x;
     const int within = blockIdx.x & 31;
     const int group = (blockIdx.x >> 5) * 8 + (within & 7), m = within >> 3;
-    if (group >= p.n_groups || (p.opts.drop_member && m == 3)) return;
+    if (group >= p.n_groups) return;
     const int T = p.T;
     const int row = group;
     constexpr int G = 1024, H = 256;
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(TGT) void lstm_train_bwd_group1_kernel(TrainGroupBw
     const bool owner = (ns & ~5) == 0;
     auto dpos = [](int n) { return (((n >> 6) * 32 + (n & 31)) << 1) + ((n >> 5) & 1); };
     u64_t* xg = p.xchg + (size_t)group * 2 * 4 * TGB1_GRAN;
-    const bool local = group_placement_local(xg, TGB1_GRAN, 256, m, flag, p.opts.limit_first) && !p.opts.agent_scope;
+    const bool local = group_placement_local(xg, TGB1_GRAN, 256, m, flag, p.opts.limit_first, p.opts.drop_member && m == 3) && !p.opts.agent_scope;
     float dh_rec = 0.f, dc_next = 0.f;
     bool failed = false;
     // what the cell backward of step t-1 reads (activations, cell states, dh from above) is requested during step t
