@@ -69,14 +69,29 @@ def mfma_table(sub, dst_name):
             continue
         b, g = sum(busy) / len(busy), sum(gui) / len(gui)
         ns = sum(d["ns"]) / len(d["ns"])
-        rows.append((k[:110], len(busy), ns / 1e3, b, g, b / (g / 8 * 1024), g / 8 / ns))
+        rows.append([k[:110], len(busy), ns / 1e3, b, g, b / (g / 8 * 1024), g / 8 / ns])
+    if not rows:
+        return
+    # GRBM_GUI_ACTIVE is not kernel-exclusive: it also counts the dispatch window around the kernel, so for kernels of
+    # tens of microseconds "GUI_ACTIVE / 8 / kernel time" reads 2.9-3.5 GHz on a part that runs <= 2.4 GHz and
+    # busy / GUI understates the utilisation by an unknown factor.  The reference clock is
+    # therefore taken from the LONGEST kernel of the collection (>= 200 us: the window error is < 2 %), and the
+    # time-based utilisation busy / (1024 SIMDs x kernel time x that clock) is reported beside the GUI-based one;
+    # rows whose own GUI clock is implausible (> 2.45 GHz) are flagged and only their time-based figure is meaningful
+    # (it still assumes the long kernel's clock: a short non-MFMA kernel may clock higher, which only lowers its figure).
+    longest = max(rows, key=lambda r: r[2])
+    clk_ref = min(longest[6], 2.4) if longest[2] >= 200.0 else 2.1
     with open(f"{dst}/{dst_name}", "w") as f:
-        f.write("kernel,launches,avg_us_under_pmc,mfma_busy_cycles,gui_active,mfma_util,clock_ghz\n")
+        f.write(f"# clock reference {clk_ref:.3f} GHz from the longest kernel ({longest[0][:60]}, {longest[2]:.0f} us)\n")
+        f.write("kernel,launches,avg_us_under_pmc,mfma_busy_cycles,gui_active,mfma_util_gui_window,clock_ghz_gui_window,"
+                "mfma_util_time_based,gui_window_exclusive\n")
         for r in sorted(rows, key=lambda r: -r[2]):
-            f.write(f"\"{r[0]}\",{r[1]},{r[2]:.1f},{r[3]:.0f},{r[4]:.0f},{r[5]:.4f},{r[6]:.3f}\n")
-    print(dst_name)
+            util_t = r[3] / (1024.0 * r[2] * 1e3 * clk_ref)
+            f.write(f"\"{r[0]}\",{r[1]},{r[2]:.1f},{r[3]:.0f},{r[4]:.0f},{r[5]:.4f},{r[6]:.3f},{util_t:.4f},"
+                    f"{'yes' if r[6] <= 2.45 else 'NO'}\n")
+    print(dst_name, f"(clock reference {clk_ref:.2f} GHz)")
     for r in sorted(rows, key=lambda r: -r[2])[:8]:
-        print(f"  {r[0][:70]:70s} {r[2]:8.1f} us  util {r[5]:.3f}  clock {r[6]:.2f} GHz")
+        print(f"  {r[0][:70]:70s} {r[2]:8.1f} us  util(gui) {r[5]:.3f}  util(time) {r[3] / (1024.0 * r[2] * 1e3 * clk_ref):.3f}  gui clock {r[6]:.2f} GHz")
 
 mfma_table("mfma", f"pmc_mfma_busy_{tag}.csv")
 mfma_table("mfma_train", f"pmc_mfma_busy_train_{tag}.csv")
