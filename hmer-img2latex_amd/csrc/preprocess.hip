@@ -8,6 +8,9 @@
 // device work is pure integer and the result is bit-identical to the reference's.
 #include <math.h>
 
+#include <thread>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
             if (xs >= pl.new_w) {
                 v = (out_c == 1 || c == 0) ? 255 : 0;      // Image.new(mode, size, 255): white for L, (255,0,0) for RGB
             } else if (pl.need_v) {
-                const int y0 = bv[2 * y], n = bv[2 * y + 1];                // y0 already relative to the intermediate image
+                const int y0 = bv[2 * y] - (pl.need_h ? pl.ybox_first : 0), n = bv[2 * y + 1];   // Resample.c "shift bounds for vertical pass"
                 const int32_t* k = kv + (size_t)y * pl.kv_ksize;
                 int acc = 1 << (PREC - 1);
                 if (pl.need_h)
@@ -188,6 +191,29 @@ extern "C" int i2l_resample_coeffs(int filter, int in_size, int out_size, int32_
 
 extern "C" int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out) {
     return i2l_resample_coeffs(I2L_FILTER_LANCZOS, in_size, out_size, bounds_out, kk_out);
+}
+
+// n tables in one call, computed by up to `threads` host threads (the double-precision sin() of the Lanczos weights is
+// ~0.1 ms per image on one core: the whole evaluate batch would wait ~25 ms for its tables).  Entry i resamples
+// in_sizes[i] -> out_sizes[i] and writes bounds (out, 2) at out + offsets[i], weights (out, ksize) right behind them.
+extern "C" int i2l_resample_coeffs_batch(int filter, int n, const int32_t* in_sizes, const int32_t* out_sizes,
+                                         const int64_t* offsets, int32_t* out, int threads) {
+    if (n < 0 || (n > 0 && (!in_sizes || !out_sizes || !offsets || !out))) return I2L_ERR_ARG;
+    if (filter != I2L_FILTER_LANCZOS && filter != I2L_FILTER_BICUBIC) return I2L_ERR_UNSUPPORTED;
+    std::vector<int> rc((size_t)(n > 0 ? n : 1), I2L_OK);
+    auto work = [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i)
+            rc[i] = i2l_resample_coeffs(filter, in_sizes[i], out_sizes[i], out + offsets[i], out + offsets[i] + 2 * (int64_t)out_sizes[i]);
+    };
+    const int nt = threads < 1 ? 1 : (threads > n ? (n > 0 ? n : 1) : threads);
+    if (nt <= 1) work(0, n);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
+        for (auto& th : pool) th.join();
+    }
+    for (int i = 0; i < n; ++i) if (rc[i] != I2L_OK) return rc[i];
+    return I2L_OK;
 }
 
 extern "C" int i2l_preprocess_images(const uint8_t* pixels, const i2l_resize_plan* plans, const int32_t* tables, int n,

@@ -9,8 +9,7 @@ precision + libm, the arithmetic Pillow itself runs) and cached per (source size
 """
 from __future__ import annotations
 
-import ctypes
-import functools
+import os
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -19,27 +18,89 @@ import torch
 from .. import _lib
 
 
-class ResizePlan(ctypes.Structure):
-    """struct i2l_resize_plan (include/img2latex_hip.h)."""
-    _fields_ = [("src_offset", ctypes.c_int64), ("tmp_offset", ctypes.c_int64),
-                ("bh_offset", ctypes.c_int64), ("kh_offset", ctypes.c_int64),
-                ("bv_offset", ctypes.c_int64), ("kv_offset", ctypes.c_int64),
-                ("src_h", ctypes.c_int32), ("src_w", ctypes.c_int32), ("src_c", ctypes.c_int32),
-                ("new_w", ctypes.c_int32), ("ybox_first", ctypes.c_int32), ("tmp_rows", ctypes.c_int32),
-                ("need_h", ctypes.c_int32), ("need_v", ctypes.c_int32),
-                ("kh_ksize", ctypes.c_int32), ("kv_ksize", ctypes.c_int32)]
+# struct i2l_resize_plan (include/img2latex_hip.h) as a numpy record: a whole batch of plans is ONE array
+PLAN_DTYPE = np.dtype([("src_offset", "<i8"), ("tmp_offset", "<i8"), ("bh_offset", "<i8"), ("kh_offset", "<i8"),
+                       ("bv_offset", "<i8"), ("kv_offset", "<i8"), ("src_h", "<i4"), ("src_w", "<i4"), ("src_c", "<i4"),
+                       ("new_w", "<i4"), ("ybox_first", "<i4"), ("tmp_rows", "<i4"), ("need_h", "<i4"), ("need_v", "<i4"),
+                       ("kh_ksize", "<i4"), ("kv_ksize", "<i4")])
+assert PLAN_DTYPE.itemsize == 88
 
 
-@functools.lru_cache(maxsize=4096)
-def _coeffs(in_size: int, out_size: int, flt: int = _lib.FILTER_LANCZOS) -> Tuple[int, np.ndarray, np.ndarray]:
-    L = _lib.lib()
-    ksize = L.i2l_resample_ksize(flt, in_size, out_size)
-    if ksize <= 0:
-        raise ValueError(f"cannot resample {in_size} -> {out_size}")
-    bounds = np.zeros((out_size, 2), np.int32)
-    kk = np.zeros((out_size, ksize), np.int32)
-    _lib.check(L.i2l_resample_coeffs(flt, in_size, out_size, bounds.ctypes.data, kk.ctypes.data), "resample_coeffs")
-    return ksize, bounds, kk
+class _TablePool:
+    """Resampling tables resident on the device, one per (source size, target size, filter), shared by every image
+    and every batch that needs them: a batch only pays (threaded, in the library's host helper) for sizes it has not
+    seen before, and uploads nothing else but its pixels and plans.  Grow-only up to `capacity` int32 elements, then
+    reset.  One pool per device."""
+
+    def __init__(self, device: torch.device, capacity: int = 16 << 20):
+        self.device, self.capacity = device, capacity
+        self.tables = torch.empty((capacity,), dtype=torch.int32, device=device)
+        self.used = 0
+        self.index = {}            # (in, out, filter) -> (bounds offset, weights offset, ksize, first, last)
+
+    def lookup(self, keys):
+        """Makes every key resident; returns nothing (read self.index)."""
+        missing = [k for k in dict.fromkeys(keys) if k not in self.index]
+        if not missing:
+            return
+        L = _lib.lib()
+        ks = [L.i2l_resample_ksize(f, a, b) for (a, b, f) in missing]
+        if min(ks) <= 0:
+            raise ValueError("cannot resample an empty axis")
+        sizes = [b * (2 + k) for (a, b, f), k in zip(missing, ks)]
+        total = int(sum(sizes))
+        if total > self.capacity:
+            raise ValueError("resampling tables of one batch exceed the table pool")
+        if self.used + total > self.capacity:                     # full: start over (tables of earlier batches are
+            torch.cuda.current_stream(self.device).synchronize()  # dropped once nothing in flight reads them)
+            self.index.clear()
+            self.used = 0
+            return self.lookup(keys)
+        offs = np.zeros(len(missing), np.int64)
+        offs[1:] = np.cumsum(sizes[:-1])
+        host = torch.empty((total,), dtype=torch.int32).pin_memory()
+        for flt in sorted({f for (_, _, f) in missing}):
+            sel = [i for i, (_, _, f) in enumerate(missing) if f == flt]
+            ins = np.array([missing[i][0] for i in sel], np.int32)
+            outs = np.array([missing[i][1] for i in sel], np.int32)
+            o = np.ascontiguousarray(offs[sel])
+            _lib.check(L.i2l_resample_coeffs_batch(flt, len(sel), ins.ctypes.data, outs.ctypes.data, o.ctypes.data,
+                                                   host.data_ptr(), min(16, os.cpu_count() or 1)), "resample_coeffs_batch")
+        hv = host.numpy()
+        for (key, k, off) in zip(missing, ks, offs.tolist()):
+            b = key[1]
+            first = int(hv[off])
+            last = int(hv[off + 2 * (b - 1)] + hv[off + 2 * (b - 1) + 1])
+            self.index[key] = (self.used + off, self.used + off + 2 * b, k, first, last)
+        self.tables[self.used:self.used + total].copy_(host, non_blocking=True)
+        # the pinned staging block must outlive the asynchronous copy
+        torch.cuda.current_stream(self.device).synchronize()
+        self.used += total
+
+
+_POOLS = {}
+_STAGING = {}
+
+
+def _pool(dev: torch.device) -> _TablePool:
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _POOLS:
+        _POOLS[key] = _TablePool(dev)
+    return _POOLS[key]
+
+
+def _staging(dev: torch.device, nbytes: int):
+    """Two pinned uint8 blocks per device, used alternately; a block is reused only after the copy that last read it
+    has finished (its event)."""
+    key = (dev.type, dev.index)
+    st = _STAGING.setdefault(key, {"bufs": [None, None], "events": [None, None], "next": 0})
+    i = st["next"]
+    st["next"] = i ^ 1
+    if st["events"][i] is not None:
+        st["events"][i].synchronize()
+    if st["bufs"][i] is None or st["bufs"][i].numel() < nbytes:
+        st["bufs"][i] = torch.empty((max(nbytes, 1 << 20) * 5 // 4,), dtype=torch.uint8).pin_memory()
+    return st, i, st["bufs"][i]
 
 
 def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (64, 800), channels: int = 1,
@@ -49,7 +110,11 @@ def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (
 
     ``keep_aspect=False, resample="bicubic", normalize="symmetric"`` is the PIL.Image branch of the reference's
     ``Predictor._prepare_image`` instead (predictor.py:432-451): ``image.resize((W, H))`` with Pillow's default filter
-    straight to the target size, then ``x / 255 * 2 - 1`` on every channel."""
+    straight to the target size, then ``x / 255 * 2 - 1`` on every channel.
+
+    Host work per batch: one pass over the shapes, table look-ups in the device-resident pool (new sizes are computed
+    by i2l_resample_coeffs_batch on the host's cores), ONE packed copy of the pixels into pinned memory and two
+    asynchronous uploads (pixels, plans)."""
     flt = {"lanczos": _lib.FILTER_LANCZOS, "bicubic": _lib.FILTER_BICUBIC}[resample]
     normalize = 2 if normalize == "symmetric" else int(bool(normalize))
     if channels not in (1, 3):
@@ -57,56 +122,66 @@ def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (
     if not torch.cuda.is_available():
         raise RuntimeError("img2latex_amd: the preprocessing kernels need the ROCm device; there is no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     out_h, out_w = int(img_size[0]), int(img_size[1])
     n = len(images)
     if n == 0:
         return torch.empty((0, channels, out_h, out_w), dtype=torch.float32, device=dev)
-    plans = (ResizePlan * n)()
-    tables: List[np.ndarray] = []
-    pix: List[np.ndarray] = []
-    t_off = p_off = w_off = 0
-    max_tmp_px = 0
+    flats = []
+    shapes = np.empty((n, 3), np.int64)
     for i, img in enumerate(images):
-        img = np.ascontiguousarray(img)
-        if img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3):
+        if not isinstance(img, np.ndarray) or img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3):
             raise TypeError("images must be uint8 arrays of shape (H, W) or (H, W, 3)")
-        h, w = img.shape[:2]
-        if h == 0 or w == 0:
-            raise ValueError("empty image")
-        new_w = int(round(out_h * (w / h))) if keep_aspect else out_w   # transforms.py:33-36 / predictor.py:439
-        if new_w <= 0:
-            raise ValueError(f"image {i} ({h}x{w}) collapses to zero width at height {out_h}")
-        p = plans[i]
-        p.src_offset, p.src_h, p.src_w, p.src_c = p_off, h, w, 1 if img.ndim == 2 else 3
-        p.new_w, p.need_h, p.need_v = new_w, int(new_w != w), int(out_h != h)
-        kh_k, bh, kh = _coeffs(w, new_w, flt)
-        kv_k, bv, kv = _coeffs(h, out_h, flt)
-        ybox_first = int(bv[0, 0])
-        ybox_last = int(bv[out_h - 1, 0] + bv[out_h - 1, 1])
-        if p.need_h:                                              # Resample.c: shift bounds for the vertical pass
-            bv = bv.copy()
-            bv[:, 0] -= ybox_first
-            p.ybox_first, p.tmp_rows = ybox_first, ybox_last - ybox_first
-            p.tmp_offset = w_off
-            w_off += (p.tmp_rows * new_w * channels + 255) // 256 * 256
-            max_tmp_px = max(max_tmp_px, p.tmp_rows * new_w)
-        p.kh_ksize, p.kv_ksize = kh_k, kv_k
-        for arr, name in ((bh, "bh_offset"), (kh, "kh_offset"), (bv, "bv_offset"), (kv, "kv_offset")):
-            setattr(p, name, t_off)
-            tables.append(arr.reshape(-1))
-            t_off += arr.size
-        pix.append(img.reshape(-1))
-        p_off += (img.size + 255) // 256 * 256
-    pixels = np.zeros((p_off,), np.uint8)
-    for p, a in zip(plans, pix):
-        pixels[p.src_offset: p.src_offset + a.size] = a
-    d_pixels = torch.from_numpy(pixels).to(dev)
-    d_tables = torch.from_numpy(np.concatenate(tables)).to(dev)
-    d_plans = torch.from_numpy(np.frombuffer(bytes(plans), dtype=np.uint8).copy()).to(dev)
-    ws = torch.empty((max(w_off, 16),), dtype=torch.uint8, device=dev)
-    out = torch.empty((n, channels, out_h, out_w), dtype=torch.float32, device=dev)
+        shapes[i, 0], shapes[i, 1], shapes[i, 2] = img.shape[0], img.shape[1], (1 if img.ndim == 2 else 3)
+        flats.append(img.reshape(-1) if img.flags.c_contiguous else np.ascontiguousarray(img).reshape(-1))
+    h, w, c = shapes[:, 0], shapes[:, 1], shapes[:, 2]
+    if int(h.min()) == 0 or int(w.min()) == 0:
+        raise ValueError("empty image")
+    # transforms.py:33-36: int(round(target_h * (w / h))) -- Python's round() and numpy's both round half to even
+    new_w = np.round(out_h * (w / h)).astype(np.int64) if keep_aspect else np.full(n, out_w, np.int64)
+    if int(new_w.min()) <= 0:
+        bad = int(np.argmin(new_w))
+        raise ValueError(f"image {bad} ({int(h[bad])}x{int(w[bad])}) collapses to zero width at height {out_h}")
+    pool = _pool(dev)
+    hkeys = [(int(a), int(b), flt) for a, b in zip(w, new_w)]
+    vkeys = [(int(a), out_h, flt) for a in h]
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().i2l_preprocess_images(d_pixels.data_ptr(), d_plans.data_ptr(), d_tables.data_ptr(), n,
+        pool.lookup(hkeys + vkeys)
+        ent_h = np.array([pool.index[k] for k in hkeys], np.int64)
+        ent_v = np.array([pool.index[k] for k in vkeys], np.int64)
+        plans = np.zeros(n, PLAN_DTYPE)
+        sizes = h * w * c
+        src_off = np.zeros(n, np.int64)
+        src_off[1:] = np.cumsum(sizes[:-1])
+        need_h = new_w != w
+        tmp_rows = np.where(need_h, ent_v[:, 4] - ent_v[:, 3], 0)
+        tmp_bytes = (tmp_rows * new_w * channels + 255) // 256 * 256
+        tmp_off = np.zeros(n, np.int64)
+        tmp_off[1:] = np.cumsum(tmp_bytes[:-1])
+        plans["src_offset"], plans["tmp_offset"] = src_off, tmp_off
+        plans["bh_offset"], plans["kh_offset"], plans["kh_ksize"] = ent_h[:, 0], ent_h[:, 1], ent_h[:, 2]
+        plans["bv_offset"], plans["kv_offset"], plans["kv_ksize"] = ent_v[:, 0], ent_v[:, 1], ent_v[:, 2]
+        plans["src_h"], plans["src_w"], plans["src_c"], plans["new_w"] = h, w, c, new_w
+        plans["ybox_first"] = np.where(need_h, ent_v[:, 3], 0)
+        plans["tmp_rows"] = tmp_rows
+        plans["need_h"], plans["need_v"] = need_h, h != out_h
+        total_px = int(sizes.sum())
+        plan_bytes = n * PLAN_DTYPE.itemsize
+        st, slot, pinned = _staging(dev, total_px + plan_bytes + 256)
+        host = pinned.numpy()
+        np.concatenate(flats, out=host[:total_px])
+        p0 = (total_px + 255) // 256 * 256
+        host[p0:p0 + plan_bytes] = plans.view(np.uint8)
+        d_all = torch.empty((p0 + plan_bytes,), dtype=torch.uint8, device=dev)
+        d_all.copy_(pinned[:p0 + plan_bytes], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][slot] = ev
+        max_tmp_px = int((tmp_rows * new_w).max())
+        ws = torch.empty((max(int(tmp_bytes.sum()), 16),), dtype=torch.uint8, device=dev)
+        out = torch.empty((n, channels, out_h, out_w), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().i2l_preprocess_images(d_all.data_ptr(), d_all.data_ptr() + p0, pool.tables.data_ptr(), n,
                                                     max_tmp_px, channels, out_h, out_w, normalize,
                                                     ws.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "preprocess_images")
     return out

@@ -377,10 +377,15 @@ int i2l_lanczos_coeffs(int in_size, int out_size, int32_t* bounds_out, int32_t* 
 #define I2L_FILTER_BICUBIC 3
 int i2l_resample_ksize(int filter, int in_size, int out_size);
 int i2l_resample_coeffs(int filter, int in_size, int out_size, int32_t* bounds_out, int32_t* kk_out);
+/* n tables at once on up to `threads` host threads: entry i (in_sizes[i] -> out_sizes[i]) is written at out +
+ * offsets[i] as bounds (out, 2) followed by weights (out, ksize).  No global state: the threads live for the call. */
+int i2l_resample_coeffs_batch(int filter, int n, const int32_t* in_sizes, const int32_t* out_sizes,
+                              const int64_t* offsets, int32_t* out, int threads);
 
 /* One image of a ragged batch.  Offsets index `pixels` (bytes), `tables` (int32 elements) and the workspace
- * (bytes).  bv bounds must already be relative to the intermediate image when need_h (Resample.c: "Shift bounds
- * for vertical pass"). */
+ * (bytes).  Bounds are ABSOLUTE source indices as i2l_resample_coeffs writes them; when need_h the kernel itself
+ * subtracts ybox_first from the vertical ones (Resample.c: "Shift bounds for vertical pass"), so one table serves
+ * every image of the same (source size, target size). */
 typedef struct i2l_resize_plan {
     int64_t src_offset;            /* first byte of the uint8 image: (src_h, src_w) or (src_h, src_w, 3) interleaved */
     int64_t tmp_offset;            /* intermediate image (tmp_rows, new_w, out_c) uint8 in the workspace             */

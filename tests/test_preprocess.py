@@ -46,6 +46,30 @@ def test_host_coefficients_equal_oracle():
         assert np.array_equal(bounds, bo) and np.array_equal(kk, ko), (a, b)
 
 
+def test_batched_coefficient_helper_equals_single_calls():
+    """i2l_resample_coeffs_batch (host threads inside the call) writes, per entry, exactly what i2l_resample_coeffs
+    writes: bounds (out, 2) then weights (out, ksize) at the entry's offset."""
+    L = _lib.lib()
+    pairs = [(150, 240), (500, 160), (2400, 768), (64, 64), (40, 64), (200, 64), (23, 60), (17, 32), (300, 14), (811, 320)]
+    for flt in (_lib.FILTER_LANCZOS, _lib.FILTER_BICUBIC):
+        ks = [L.i2l_resample_ksize(flt, a, b) for a, b in pairs]
+        sizes = [b * (2 + k) for (a, b), k in zip(pairs, ks)]
+        offs = np.zeros(len(pairs), np.int64)
+        offs[1:] = np.cumsum(sizes[:-1])
+        out = np.full(sum(sizes), -7, np.int32)
+        ins, outs = np.array([a for a, _ in pairs], np.int32), np.array([b for _, b in pairs], np.int32)
+        for threads in (1, 4, 64):
+            out[:] = -7
+            assert L.i2l_resample_coeffs_batch(flt, len(pairs), ins.ctypes.data, outs.ctypes.data, offs.ctypes.data,
+                                               out.ctypes.data, threads) == 0
+            for (a, b), k, o in zip(pairs, ks, offs.tolist()):
+                bounds, kk = np.zeros((b, 2), np.int32), np.zeros((b, k), np.int32)
+                assert L.i2l_resample_coeffs(flt, a, b, bounds.ctypes.data, kk.ctypes.data) == 0
+                assert np.array_equal(out[o:o + 2 * b].reshape(b, 2), bounds), (a, b, threads)
+                assert np.array_equal(out[o + 2 * b:o + b * (2 + k)].reshape(b, k), kk), (a, b, threads)
+    assert L.i2l_resample_coeffs_batch(9, 1, ins.ctypes.data, outs.ctypes.data, offs.ctypes.data, out.ctypes.data, 1) < 0
+
+
 @pytest.mark.gpu
 def test_device_preprocessing_bit_exact():
     from img2latex_amd.data import preprocess_batch
