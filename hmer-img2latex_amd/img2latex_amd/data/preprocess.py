@@ -104,7 +104,8 @@ def _staging(dev: torch.device, nbytes: int):
 
 
 def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (64, 800), channels: int = 1,
-                     normalize=True, device=None, keep_aspect: bool = True, resample: str = "lanczos") -> torch.Tensor:
+                     normalize=True, device=None, keep_aspect: bool = True, resample: str = "lanczos",
+                     upload_stream=None) -> torch.Tensor:
     """`load_image` for already decoded images: uint8 arrays (H, W) ["L"] or (H, W, 3) ["RGB"], any sizes.
     Returns (n, channels, img_size[0], img_size[1]) float32 on the device.
 
@@ -114,7 +115,8 @@ def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (
 
     Host work per batch: one pass over the shapes, table look-ups in the device-resident pool (new sizes are computed
     by i2l_resample_coeffs_batch on the host's cores), ONE packed copy of the pixels into pinned memory and two
-    asynchronous uploads (pixels, plans)."""
+    asynchronous upload (pixels + plans).  ``upload_stream``: run that upload on a side stream (the kernels, on the
+    current stream, wait for it) so that it overlaps whatever the current stream is still doing."""
     flt = {"lanczos": _lib.FILTER_LANCZOS, "bicubic": _lib.FILTER_BICUBIC}[resample]
     normalize = 2 if normalize == "symmetric" else int(bool(normalize))
     if channels not in (1, 3):
@@ -173,11 +175,18 @@ def preprocess_batch(images: Sequence[np.ndarray], img_size: Tuple[int, int] = (
         np.concatenate(flats, out=host[:total_px])
         p0 = (total_px + 255) // 256 * 256
         host[p0:p0 + plan_bytes] = plans.view(np.uint8)
-        d_all = torch.empty((p0 + plan_bytes,), dtype=torch.uint8, device=dev)
-        d_all.copy_(pinned[:p0 + plan_bytes], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        cur = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(upload_stream if upload_stream is not None else cur):
+            # allocated under the uploading stream: memory the caching allocator hands out there has no pending work
+            # of the compute stream on it, so the copy need not wait for the previous batch's kernels
+            d_all = torch.empty((p0 + plan_bytes,), dtype=torch.uint8, device=dev)
+            d_all.copy_(pinned[:p0 + plan_bytes], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         st["events"][slot] = ev
+        if upload_stream is not None:
+            cur.wait_event(ev)
+            d_all.record_stream(cur)
         max_tmp_px = int((tmp_rows * new_w).max())
         ws = torch.empty((max(int(tmp_bytes.sum()), 16),), dtype=torch.uint8, device=dev)
         out = torch.empty((n, channels, out_h, out_w), dtype=torch.float32, device=dev)

@@ -56,8 +56,11 @@ def sequence_statistics(predictions: Sequence[Sequence[int]], targets: Sequence[
 
 
 def device_sequence_statistics(p_ids: torch.Tensor, p_len: torch.Tensor, t_ids: torch.Tensor, t_len: torch.Tensor,
-                               n: int = 4, pad_token_id: int = 0, _max_len: int = None) -> Dict[str, torch.Tensor]:
-    """Same for id matrices that already live on the device ((P, W) int32 + lengths), e.g. the decode kernel's output."""
+                               n: int = 4, pad_token_id: int = 0, _max_len: int = None, defer: bool = False):
+    """Same for id matrices that already live on the device ((P, W) int32 + lengths), e.g. the decode kernel's output.
+    ``defer=True`` returns the statistics as ONE device tensor (P, 9) int32 = [lev | match x4 | tla x2 | gen_len |
+    true_len] without touching the host (``unpack_statistics`` splits its host copy), so a caller can overlap the next
+    batch's host work with this one's kernels."""
     for name, t in (("pred ids", p_ids), ("pred lengths", p_len), ("target ids", t_ids), ("target lengths", t_len)):
         _lib.require_gpu(t, name, torch.int32)
     pairs = p_ids.shape[0]
@@ -79,7 +82,14 @@ def device_sequence_statistics(p_ids: torch.Tensor, p_len: torch.Tensor, t_ids: 
         p_ids.data_ptr(), p_len.data_ptr(), p_ids.stride(0), t_ids.data_ptr(), t_len.data_ptr(), t_ids.stride(0), pairs,
         max_len, int(n), int(pad_token_id), lev.data_ptr(), match.data_ptr(), tla.data_ptr(), _lib.stream_ptr()),
         "sequence_metrics")
-    return dict(lev=lev.cpu(), match=match.cpu(), tla=tla.cpu(), gen_len=p_len.cpu(), true_len=t_len.cpu())
+    packed = torch.cat([lev[:, None], match, tla, p_len[:, None], t_len[:, None]], dim=1)
+    return packed if defer else unpack_statistics(packed.cpu())
+
+
+def unpack_statistics(packed_host: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """(P, 9) int32 host tensor of device_sequence_statistics(defer=True) -> the dict of the other entry points."""
+    return dict(lev=packed_host[:, 0], match=packed_host[:, 1:5], tla=packed_host[:, 5:7], gen_len=packed_host[:, 7],
+                true_len=packed_host[:, 8])
 
 
 def _lev_similarity(raw_distance: int, rows: int, cols: int) -> float:

@@ -207,13 +207,37 @@ class Predictor:
 
         Returns {"bleu", "levenshtein", "batch_size"} as ``calculate_metrics`` does, plus "pred_ids"/"pred_len"
         (device tensors) for callers that also want the strings."""
+        return self._evaluate_finish(self._evaluate_launch(images, targets, max_length))
+
+    def evaluate_stream(self, batches, max_length: Optional[int] = None):
+        """``evaluate_batch`` over an iterable of (images, targets), one result per batch in order, software-pipelined:
+        the host work of batch i+1 (shape pass, packing the ragged pages into pinned memory, their upload on a side
+        stream) runs while the device is still busy with batch i, and the host only waits for batch i's statistics
+        after batch i+1 has been enqueued.  This is the loop of cli.py:449-495."""
+        pending = None
+        for images, targets in batches:
+            handle = self._evaluate_launch(images, targets, max_length, side_upload=True)
+            if pending is not None:
+                yield self._evaluate_finish(pending)
+            pending = handle
+        if pending is not None:
+            yield self._evaluate_finish(pending)
+
+    def _evaluate_launch(self, images, targets: torch.Tensor, max_length: Optional[int], side_upload: bool = False,
+                         rows_per_workgroup: int = 0):
+        """Enqueues the whole chain of one batch and the copy of its statistics to pinned memory; no host wait."""
         from . import metrics as M
         L = _lib.lib()
         tk = self.tokenizer
+        raw = images
         if not isinstance(images, torch.Tensor):
             from ..data import preprocess_batch
             enc_mod = self.model.encoder
-            images = preprocess_batch(list(images), (enc_mod.img_height, enc_mod.img_width), enc_mod.channels, True)
+            if side_upload and getattr(self, "_up_stream", None) is None:
+                self._up_stream = torch.cuda.Stream(self.device)
+            with torch.cuda.device(self.device):
+                images = preprocess_batch(list(images), (enc_mod.img_height, enc_mod.img_width), enc_mod.channels, True,
+                                          upload_stream=self._up_stream if side_upload else None)
         x = self._as_batch(images)
         B = x.shape[0]
         T = int(max_length if max_length is not None else tk.max_sequence_length)
@@ -236,21 +260,37 @@ class Predictor:
         t_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
         p_len = torch.empty((B,), dtype=torch.int32, device=dev)
         t_len = torch.empty((B,), dtype=torch.int32, device=dev)
-        _lib.check(L.i2l_compact_ids(tgt.data_ptr(), B, tgt.shape[1], tgt.stride(0), -1, self._pad.data_ptr(), 1,
-                                     t_ids.data_ptr(), W, t_len.data_ptr(), _lib.stream_ptr()), "compact_ids")
-        with torch.no_grad():
-            enc = self.model.encoder(x)
-            for rows_per_workgroup in (0, 1):       # 1 = the timeout fallback of Seq2SeqModel.greedy_ids_host
+        with torch.cuda.device(dev):
+            _lib.check(L.i2l_compact_ids(tgt.data_ptr(), B, tgt.shape[1], tgt.stride(0), -1, self._pad.data_ptr(), 1,
+                                         t_ids.data_ptr(), W, t_len.data_ptr(), _lib.stream_ptr()), "compact_ids")
+            with torch.no_grad():
+                enc = self.model.encoder(x)
                 ids, _ = self.model.greedy_ids(enc, tk.start_token_id, tk.end_token_id, T, stop=_lib.STOP_STICKY,
                                                select=_lib.SELECT_SOFTMAX, rows_per_workgroup=rows_per_workgroup)
                 _lib.check(L.i2l_compact_ids(ids.data_ptr(), B, T, ids.stride(0), int(tk.end_token_id),
                                              self._drop.data_ptr(), len(drop), p_ids.data_ptr(), W, p_len.data_ptr(),
                                              _lib.stream_ptr()), "compact_ids")
-                st = M.device_sequence_statistics(p_ids, p_len, t_ids, t_len, 4, tk.pad_token_id, _max_len=W)
-                if not _lib.ids_timed_out(ids[:, :1].cpu()):       # the statistics copy above already synchronised
-                    break
-        out = M.metrics_from_statistics(st)
-        out["pred_ids"], out["pred_len"] = p_ids, p_len
+                packed = M.device_sequence_statistics(p_ids, p_len, t_ids, t_len, 4, tk.pad_token_id, _max_len=W, defer=True)
+            # statistics + the first id of every row (-3 = the grouped decode timed out) in ONE device->host copy
+            packed = torch.cat([packed, ids[:, :1]], dim=1)
+            host = torch.empty(packed.shape, dtype=torch.int32).pin_memory()
+            host.copy_(packed, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        return dict(host=host, done=done, keep=(packed, x, tgt), p_ids=p_ids, p_len=p_len, raw=(raw, targets, max_length),
+                    rows_per_workgroup=rows_per_workgroup)
+
+    def _evaluate_finish(self, h) -> Dict:
+        from . import metrics as M
+        h["done"].synchronize()
+        host = h["host"]
+        if _lib.ids_timed_out(host[:, 9:10]) and h["rows_per_workgroup"] == 0:
+            # the timeout fallback of Seq2SeqModel.greedy_ids_host: the row-per-workgroup kernel needs no partner
+            raw, targets, max_length = h["raw"]
+            return self._evaluate_finish(self._evaluate_launch(raw, targets, max_length, rows_per_workgroup=1))
+        _lib.check_ids(host[:, 9:10])
+        out = M.metrics_from_statistics(M.unpack_statistics(host[:, :9]))
+        out["pred_ids"], out["pred_len"] = h["p_ids"], h["p_len"]
         return out
 
     def predict_batch(self, images, beam_size: int = 0, max_length: int = 141, temperature: float = 1.0,
