@@ -273,7 +273,14 @@ class Predictor:
                 packed = M.device_sequence_statistics(p_ids, p_len, t_ids, t_len, 4, tk.pad_token_id, _max_len=W, defer=True)
             # statistics + the first id of every row (-3 = the grouped decode timed out) in ONE device->host copy
             packed = torch.cat([packed, ids[:, :1]], dim=1)
-            host = torch.empty(packed.shape, dtype=torch.int32).pin_memory()
+            # pinned landing buffers are reused (registering pinned memory costs ~1 ms): a ring of 4, more than the
+            # two batches evaluate_stream ever has in flight
+            ring = self.__dict__.setdefault("_host_ring", {"bufs": [None] * 4, "next": 0})
+            slot = ring["next"]
+            ring["next"] = (slot + 1) % 4
+            if ring["bufs"][slot] is None or ring["bufs"][slot].numel() < packed.numel():
+                ring["bufs"][slot] = torch.empty((packed.numel(),), dtype=torch.int32).pin_memory()
+            host = ring["bufs"][slot][:packed.numel()].view(packed.shape)
             host.copy_(packed, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
