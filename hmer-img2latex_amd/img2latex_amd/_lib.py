@@ -106,6 +106,15 @@ _SIGNATURES.update({
     "i2l_lanczos_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "i2l_preprocess_images": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p]),
+    "i2l_bn_train_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),
+    "i2l_bn_train_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                                      c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_bn_train_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int, ctypes.c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_im2col_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "i2l_col2im_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "i2l_maxpool3x3s2_bf16_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "i2l_global_avgpool_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_decoder_group_status_offset": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "i2l_resample_ksize": (c_int, [c_int, c_int, c_int]),
     "i2l_resample_coeffs": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -110,8 +110,62 @@ class CNNEncoderFn(torch.autograd.Function):
         return (None, None) + tuple(grads[n] for n, _ in named)
 
 
+class ResNetEncoderFn(torch.autograd.Function):
+    """ResNetEncoder.forward in training mode (encoder.py:231-249 under model.train()) with a HIP backward.
+    inputs: encoder module, images, then the TRAINABLE parameters in ``encoder.parameters()`` order."""
+
+    @staticmethod
+    def forward(ctx, encoder, x, *params):
+        out, state = encoder_train_forward(encoder, x.detach())
+        ctx.encoder, ctx.state = encoder, state
+        return out
+
+    @staticmethod
+    def backward(ctx, denc):
+        enc = ctx.encoder
+        named = [(n, p_) for n, p_ in enc.named_parameters() if p_.requires_grad]
+        grads = {n: torch.zeros_like(p_) for n, p_ in named}
+        encoder_train_backward(enc, ctx.state, denc.contiguous(), grads)
+        ctx.state = None
+        return (None, None) + tuple(grads[n] for n, _ in named)
+
+
+def _resnet_train_forward(encoder, x):
+    tape = {}
+    feat = encoder._trunk_train(x, tape)
+    out = encoder._head(feat)
+    tape.update(feat=feat, out=out)
+    return out, tape
+
+
+def _resnet_train_backward(enc, tape, denc, grads, after_linear=None):
+    """``grads``: name -> tensor for the TRAINABLE parameters of the encoder (``named_parameters()`` names)."""
+    L = _lib.lib()
+    denc = _lib.require_gpu(denc, "d encoder_output")
+    feat, out = tape["feat"], tape["out"]
+    B, K = feat.shape
+    E = enc.embedding_dim
+    lin = enc.embedding_layer
+    dev = denc.device
+    dfeat = torch.empty_like(feat)
+    dw = grads.get("embedding_layer.weight")
+    db = grads.get("embedding_layer.bias")
+    dw = dw if dw is not None else torch.empty_like(lin.weight)
+    db = db if db is not None else torch.empty_like(lin.bias)
+    nbytes = L.i2l_linear_bwd_workspace_bytes(B, K, E)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(L.i2l_linear_bias_act_bwd(feat.data_ptr(), lin.weight.detach().data_ptr(), out.data_ptr(), denc.data_ptr(),
+                                         dfeat.data_ptr(), dw.data_ptr(), db.data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
+                                         0, _lib.stream_ptr()), "linear_bias_act_bwd")
+    if after_linear is not None:
+        after_linear()
+    enc._trunk_backward(tape, dfeat, grads)
+
+
 def encoder_train_forward(encoder, x):
     x = _lib.require_gpu(x, "images")
+    if hasattr(encoder, "_trunk_train"):                  # ResNetEncoder
+        return _resnet_train_forward(encoder, x)
     amax, blocks = [], []
     out = encoder._forward_impl(x, argmax_out=amax, blocks_out=blocks)
     return out, dict(x=x, blocks=blocks, amax=amax, out=out)
@@ -120,6 +174,8 @@ def encoder_train_forward(encoder, x):
 def encoder_train_backward(enc, state, denc, grads, after_linear=None):
     """Fills ``grads`` (``encoder.named_parameters()`` names) from d(encoder_output).  ``after_linear`` is called once the
     FC layer's backward has been enqueued (TrainStep starts the early part of the gradient all-reduce there)."""
+    if hasattr(enc, "_trunk_train"):                      # ResNetEncoder
+        return _resnet_train_backward(enc, state, denc, grads, after_linear)
     L = _lib.lib()
     denc = _lib.require_gpu(denc, "d encoder_output")
     dev = denc.device

@@ -41,9 +41,12 @@ class TrainStep:
         # stack's parameters go LAST: their gradients are the last the backward pass produces, so everything in front
         # of them can be all-reduced while the conv backward still runs (dp.OverlappedAllReduce)
         self.offsets: Dict[str, int] = {}
-        named = list(model.named_parameters())
-        late = [(n, p) for n, p in named if n.startswith("encoder.cnn_layers.")]
-        early = [(n, p) for n, p in named if not n.startswith("encoder.cnn_layers.")]
+        # only what requires a gradient is optimised: torch.optim.Adam skips parameters whose .grad is None, i.e. the
+        # frozen part of a ResNet backbone (encoder.py:201-210) gets neither an update nor weight decay
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        is_late = lambda n: n.startswith("encoder.cnn_layers.") or n.startswith("encoder.resnet.")
+        late = [(n, p) for n, p in named if is_late(n)]
+        early = [(n, p) for n, p in named if not is_late(n)]
         off = 0
         for name, p in early + late:
             if late and name == late[0][0]:
@@ -60,7 +63,7 @@ class TrainStep:
         self.stats = torch.zeros(4, dtype=torch.float32, device=dev)
         self.grad_views: Dict[str, torch.Tensor] = {}
         with torch.no_grad():
-            for name, p in model.named_parameters():
+            for name, p in named:
                 o = self.offsets[name]
                 view = self.flat_params[o:o + p.numel()].view_as(p)
                 view.copy_(p)
@@ -150,6 +153,9 @@ class TrainStep:
         state, params = {}, []
         applied = self.applied_steps()
         for i, (name, p) in enumerate(self.model.named_parameters()):
+            if name not in self.offsets:                      # frozen: torch's Adam holds no state for it either
+                params.append(i)
+                continue
             o = self.offsets[name]
             state[i] = {"step": torch.tensor(float(applied)),
                         "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).detach().cpu().clone(),
@@ -166,6 +172,8 @@ class TrainStep:
         names = [n for n, _ in self.model.named_parameters()]
         for i, st in sd.get("state", {}).items():
             name = names[int(i)]
+            if name not in self.offsets:
+                continue
             p = dict(self.model.named_parameters())[name]
             o = self.offsets[name]
             self.exp_avg[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])

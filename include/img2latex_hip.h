@@ -138,6 +138,38 @@ int i2l_maxpool3x3s2_bf16_fwd(const void* x, void* y, int B, int H, int W, int C
 /* nn.AdaptiveAvgPool2d(1) + Flatten: NHWC bf16 (B,H,W,C) -> fp32 (B,C). */
 int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H, int W, int C, i2l_stream_t stream);
 
+/* ResNet encoder in TRAINING mode (encoder.py:185-249 under model.train(): every BatchNorm2d of the torchvision trunk
+ * normalises with batch statistics and updates its running statistics -- the frozen ones too, freeze_backbone only
+ * clears requires_grad, :201-210 -- and layer4 + the Linear, or with freeze_backbone=False every layer, get gradients).
+ * The convolutions run on i2l_conv_bn_act_bf16_fwd with an identity BatchNorm (raw conv output z, NHWC bf16 = a
+ * row-major (M = B*H*W, C) matrix, C % 8 == 0); gradients are fp32 NHWC.
+ *   fwd: mean / biased variance of z per channel; running_* (may both be NULL) <- (1 - momentum) * running + momentum *
+ *        (mean, UNBIASED variance); y = act(bf16(gamma * (z - mean) * invstd + beta) + residual); save_mean / save_invstd (C)
+ *   bwd: g = dy masked by y_relu > 0 (y_relu NULL: no ReLU);  dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));
+ *        dgamma = sum g * xhat, dbeta = sum g (either may be NULL); dres (may be NULL) = g (or += g): the gradient of
+ *        the residual branch. */
+size_t i2l_bn_train_workspace_bytes(int64_t M, int C);
+int i2l_bn_train_fwd_bf16(const void* z, const void* residual, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, int relu, void* y,
+                          float* save_mean, float* save_invstd, int64_t M, int C, void* workspace,
+                          size_t workspace_bytes, i2l_stream_t stream);
+int i2l_bn_train_bwd_bf16(const float* dy, const void* y_relu, const void* z, const float* gamma, const float* save_mean,
+                          const float* save_invstd, float* dz, float* dgamma, float* dbeta, float* dres,
+                          int dres_accumulate, int64_t M, int C, void* workspace, size_t workspace_bytes,
+                          i2l_stream_t stream);
+/* Convolution gradients as GEMMs: col (B*Ho*Wo, Cin*kh*kw) fp32 with the column order (ci, ky, kx) of the weight
+ * tensor, so that i2l_linear_bias_act_bwd(x = col, w = weight viewed (Cout, Cin*kh*kw), dy = dz) yields dw in the
+ * weight's own layout and dcol; i2l_col2im_f32 gathers dcol back to dx (B,H,W,Cin) NHWC fp32 (deterministic).
+ * x_kind: 0 = NHWC bf16, 1 = NHWC fp32, 2 = NCHW fp32 (the image batch of the stem). */
+int i2l_im2col_f32(const void* x, int x_kind, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                   float* col, i2l_stream_t stream);
+int i2l_col2im_f32(const float* dcol, int B, int H, int W, int C, int kh, int kw, int stride, int pad, float* dx,
+                   int accumulate, i2l_stream_t stream);
+/* nn.MaxPool2d(3, 2, 1) backward (x NHWC bf16 = the forward input, dy / dx fp32 NHWC; the first maximum of a window
+ * takes its gradient, as ATen) and nn.AdaptiveAvgPool2d(1) backward (dfeat (B,C) -> dx (B,H,W,C)). */
+int i2l_maxpool3x3s2_bf16_bwd(const void* x, const float* dy, float* dx, int B, int H, int W, int C, i2l_stream_t stream);
+int i2l_global_avgpool_bwd_f32(const float* dfeat, float* dx, int B, int H, int W, int C, i2l_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Decoder (reference img2latex/model/decoder.py, seq2seq.py, predictor.py)
  * ---------------------------------------------------------------------- */

@@ -48,3 +48,62 @@ def resnet_trunk(sd: SD, model_name: str, x: torch.Tensor, prefix: str = "encode
 def resnet_encoder(sd: SD, model_name: str, x: torch.Tensor) -> torch.Tensor:
     feat = resnet_trunk(sd, model_name, x)
     return F.relu(F.linear(feat, sd["encoder.embedding_layer.weight"], sd["encoder.embedding_layer.bias"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Training mode (encoder.py:185-249 under model.train()): BatchNorm with BATCH statistics + running-statistic
+# updates, gradients by torch autograd.  PARITY UNPINNED like the forward.  `emulate_bf16=True` rounds to bf16 at the
+# points where the HIP path stores bf16 (conv operands, raw conv output z, the normalised value, the activation) with a
+# straight-through gradient, so that a comparison isolates kernel defects from the precision of the bf16 data path;
+# `emulate_bf16=False` is the plain fp32 (or fp64) computation of the reference's modules.
+# ---------------------------------------------------------------------------------------------------------------
+def _rnd(t: torch.Tensor, on: bool) -> torch.Tensor:
+    if not on:
+        return t
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
+def _bn_train(sd: SD, key: str, z: torch.Tensor, new_stats: Dict[str, torch.Tensor], emulate: bool) -> torch.Tensor:
+    rm, rv = sd[key + ".running_mean"].clone().to(z.dtype), sd[key + ".running_var"].clone().to(z.dtype)
+    y = F.batch_norm(z, rm, rv, sd[key + ".weight"], sd[key + ".bias"], training=True, momentum=0.1, eps=1e-5)
+    new_stats[key + ".running_mean"], new_stats[key + ".running_var"] = rm, rv
+    return _rnd(y, emulate)
+
+
+def resnet_trunk_train(sd: SD, model_name: str, x: torch.Tensor, new_stats: Dict[str, torch.Tensor],
+                       emulate_bf16: bool = False, prefix: str = "encoder.resnet.") -> torch.Tensor:
+    kind, counts = BLOCKS[model_name]
+    e = emulate_bf16
+    conv = lambda t, w, **kw: _rnd(F.conv2d(_rnd(t, e), _rnd(w, e), **kw), e)
+    x = F.relu(_bn_train(sd, prefix + "1", conv(x, sd[prefix + "0.weight"], stride=2, padding=3), new_stats, e))
+    x = F.max_pool2d(x, 3, stride=2, padding=1)
+    for li, n in enumerate(counts):
+        for bi in range(n):
+            p = f"{prefix}{4 + li}.{bi}."
+            stride = 2 if (li > 0 and bi == 0) else 1
+            identity = x
+            if kind == "bottleneck":
+                o = F.relu(_bn_train(sd, p + "bn1", conv(x, sd[p + "conv1.weight"]), new_stats, e))
+                o = F.relu(_bn_train(sd, p + "bn2", conv(o, sd[p + "conv2.weight"], stride=stride, padding=1), new_stats, e))
+                o = _bn_train(sd, p + "bn3", conv(o, sd[p + "conv3.weight"]), new_stats, e)
+            else:
+                o = F.relu(_bn_train(sd, p + "bn1", conv(x, sd[p + "conv1.weight"], stride=stride, padding=1), new_stats, e))
+                o = _bn_train(sd, p + "bn2", conv(o, sd[p + "conv2.weight"], padding=1), new_stats, e)
+            if p + "downsample.0.weight" in sd:
+                identity = _bn_train(sd, p + "downsample.1", conv(x, sd[p + "downsample.0.weight"], stride=stride), new_stats, e)
+            x = _rnd(F.relu(o + identity), e)
+    return F.adaptive_avg_pool2d(x, 1).flatten(1)
+
+
+def resnet_encoder_train_step(sd: SD, model_name: str, x: torch.Tensor, dout: torch.Tensor, trainable,
+                              emulate_bf16: bool = False, dtype=torch.float32):
+    """Forward in training mode + backward of sum(out * dout).  `trainable`: names (with the `encoder.` prefix) that
+    require a gradient.  Returns (out, {name: grad}, {running statistic name: new value})."""
+    sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for n in trainable:
+        sd[n].requires_grad_(True)
+    new_stats: Dict[str, torch.Tensor] = {}
+    feat = resnet_trunk_train(sd, model_name, x.to(dtype), new_stats, emulate_bf16)
+    out = F.relu(F.linear(feat, sd["encoder.embedding_layer.weight"], sd["encoder.embedding_layer.bias"]))
+    (out * dout.to(dtype)).sum().backward()
+    return out.detach(), {n: sd[n].grad.detach() for n in trainable}, {k: v.detach() for k, v in new_stats.items()}

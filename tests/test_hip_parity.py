@@ -598,9 +598,11 @@ def test_resnet_encoder_vs_oracle(model_name, hw):
     # bf16 activations through 18-50 layers: a few 1e-2 relative to the feature scale
     assert float((got_feat - want_feat).abs().max()) <= 4e-2 * float(want_feat.abs().max())
     assert float((got - want).abs().max()) <= 4e-2 * max(1.0, float(want.abs().max()))
-    enc.train()
-    with pytest.raises(NotImplementedError):
-        enc(x.to(DEV))
+    enc.train()                                       # training mode: batch statistics (tests/test_resnet_training.py)
+    with torch.no_grad():
+        tr = enc(x.to(DEV))
+    assert tr.shape == (3, 64) and torch.isfinite(tr).all() and not torch.equal(tr.cpu(), got)
+    enc.eval()
 
 
 def test_predictor_and_checkpoint_roundtrip(tmp_path):
