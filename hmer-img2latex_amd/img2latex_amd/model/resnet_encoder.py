@@ -110,6 +110,7 @@ class ResNetEncoder(nn.Module):
         self.cache_packed_weights = True
         self.kernel_flags = 0      # _lib.FLAG_RESNET_NO_RING / FLAG_RESNET_IM2COL_STEM / flag_resnet_ring_depth(n)
         self.trace = None          # a list here receives (conv, bn, x, residual, y, relu, nchw_f32) of every launch
+        self.trace_bwd = None      # a list here receives every unit's backward: dict(unit, dy, dz, dx, dres, names)
 
     # ------------------------------------------------------------------
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -249,7 +250,7 @@ class ResNetEncoder(nn.Module):
                 torch.autograd.graph.increment_version(t)
         if tape is not None:
             tape.append(dict(conv=conv, bn=bn, x=x, in_shape=shape, nchw=nchw_f32, z=z, y=y, relu=relu, mean=mean,
-                             invstd=invstd, out_shape=(B, Ho, Wo, co)))
+                             invstd=invstd, out_shape=(B, Ho, Wo, co), residual=residual))
         return y, (B, Ho, Wo, co)
 
     def _trunk_train(self, x: torch.Tensor, tape) -> torch.Tensor:
@@ -345,7 +346,10 @@ class ResNetEncoder(nn.Module):
                                            dz.data_ptr(), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dres),
                                            1 if dres_accumulate else 0, M, co, ws.data_ptr(), nb, _lib.stream_ptr()),
                    "bn_train_bwd_bf16")
-        return self._conv_backward(u, dz, need_dx, grads, nm_conv)
+        dx = self._conv_backward(u, dz, need_dx, grads, nm_conv)
+        if self.trace_bwd is not None:
+            self.trace_bwd.append(dict(unit=u, dy=dy, dz=dz, dx=dx, dres=dres, conv_name=nm_conv, bn_name=nm_bn))
+        return dx
 
     def _trunk_backward(self, tape, dfeat: torch.Tensor, grads) -> None:
         """d(trunk features) (B, C) -> gradients of every trainable trunk parameter (``grads``: encoder-relative names)."""
