@@ -71,11 +71,16 @@ def _bn_train(sd: SD, key: str, z: torch.Tensor, new_stats: Dict[str, torch.Tens
 
 
 def resnet_trunk_train(sd: SD, model_name: str, x: torch.Tensor, new_stats: Dict[str, torch.Tensor],
-                       emulate_bf16: bool = False, prefix: str = "encoder.resnet.") -> torch.Tensor:
+                       emulate_bf16: bool = False, prefix: str = "encoder.resnet.", taps=None) -> torch.Tensor:
+    """`taps`: a dict that receives the activation after every unit, keyed by the conv's state_dict prefix."""
     kind, counts = BLOCKS[model_name]
     e = emulate_bf16
+    def tap(key, t):
+        if taps is not None:
+            taps[key] = t.detach()
+        return t
     conv = lambda t, w, **kw: _rnd(F.conv2d(_rnd(t, e), _rnd(w, e), **kw), e)
-    x = F.relu(_bn_train(sd, prefix + "1", conv(x, sd[prefix + "0.weight"], stride=2, padding=3), new_stats, e))
+    x = tap(prefix + "0", F.relu(_bn_train(sd, prefix + "1", conv(x, sd[prefix + "0.weight"], stride=2, padding=3), new_stats, e)))
     x = F.max_pool2d(x, 3, stride=2, padding=1)
     for li, n in enumerate(counts):
         for bi in range(n):
@@ -83,15 +88,17 @@ def resnet_trunk_train(sd: SD, model_name: str, x: torch.Tensor, new_stats: Dict
             stride = 2 if (li > 0 and bi == 0) else 1
             identity = x
             if kind == "bottleneck":
-                o = F.relu(_bn_train(sd, p + "bn1", conv(x, sd[p + "conv1.weight"]), new_stats, e))
-                o = F.relu(_bn_train(sd, p + "bn2", conv(o, sd[p + "conv2.weight"], stride=stride, padding=1), new_stats, e))
+                o = tap(p + "conv1", F.relu(_bn_train(sd, p + "bn1", conv(x, sd[p + "conv1.weight"]), new_stats, e)))
+                o = tap(p + "conv2", F.relu(_bn_train(sd, p + "bn2", conv(o, sd[p + "conv2.weight"], stride=stride, padding=1), new_stats, e)))
                 o = _bn_train(sd, p + "bn3", conv(o, sd[p + "conv3.weight"]), new_stats, e)
+                last = p + "conv3"
             else:
-                o = F.relu(_bn_train(sd, p + "bn1", conv(x, sd[p + "conv1.weight"], stride=stride, padding=1), new_stats, e))
+                o = tap(p + "conv1", F.relu(_bn_train(sd, p + "bn1", conv(x, sd[p + "conv1.weight"], stride=stride, padding=1), new_stats, e)))
                 o = _bn_train(sd, p + "bn2", conv(o, sd[p + "conv2.weight"], padding=1), new_stats, e)
+                last = p + "conv2"
             if p + "downsample.0.weight" in sd:
-                identity = _bn_train(sd, p + "downsample.1", conv(x, sd[p + "downsample.0.weight"], stride=stride), new_stats, e)
-            x = _rnd(F.relu(o + identity), e)
+                identity = tap(p + "downsample.0", _bn_train(sd, p + "downsample.1", conv(x, sd[p + "downsample.0.weight"], stride=stride), new_stats, e))
+            x = tap(last, _rnd(F.relu(o + identity), e))
     return F.adaptive_avg_pool2d(x, 1).flatten(1)
 
 
