@@ -139,6 +139,37 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
         record(f"{name} freeze={freeze} train backward, worst unit: {k} vs fp32 autograd of the unit [rel to max]", v)
     # the HIP backward reads the bf16-rounded z and y (ReLU mask, xhat): a few 1e-3 of the maximum per unit
     assert max(wb.values()) <= 3e-2, wb
+    # ---- (2b) the ROUTING between the units, exactly: every unit's upstream gradient is the sum of what its consumers
+    #           produced (main path, residual branch / downsample), the head of the chain is the average-pool backward of
+    #           d(features), the stem's is the max-pool backward (checked against torch's on the same input)
+    by_unit = {id(r["unit"]): r for r in bwd}
+    units, blocks = tape["units"], tape["blocks"]
+    Bf, Hf, Wf, Cf = tape["final_shape"]
+    dfeat_chain = by_unit[id(units[blocks[-1]["main"][-1]])]["dy"]
+    assert torch.equal(dfeat_chain, dfeat_chain[:, :1, :1, :].expand(Bf, Hf, Wf, Cf))       # constant over positions
+    for bi in reversed(range(len(blocks))):
+        rec = blocks[bi]
+        main, down = rec["main"], rec["down"]
+        if id(units[main[-1]]) not in by_unit:
+            break
+        r_last = by_unit[id(units[main[-1]])]
+        for a, b in zip(main[:-1], main[1:]):                    # main path: dy of a unit IS the dx of the next one
+            if id(units[a]) in by_unit:
+                assert by_unit[id(units[a])]["dy"] is by_unit[id(units[b])]["dx"]
+        if down is not None and id(units[down]) in by_unit:
+            assert by_unit[id(units[down])]["dy"] is r_last["dres"]
+        if bi > 0 and id(units[blocks[bi - 1]["main"][-1]]) in by_unit:
+            r_first = by_unit[id(units[main[0]])]
+            want_dh = r_first["dx"] + (by_unit[id(units[down])]["dx"] if down is not None else r_last["dres"])
+            assert torch.equal(by_unit[id(units[blocks[bi - 1]["main"][-1]])]["dy"], want_dh), bi
+    if first_trainable == 0:                                     # stem: max-pool backward of the first block's input gradient
+        r0 = by_unit[id(units[0])]
+        b0 = blocks[0]
+        r_first, r_last0 = by_unit[id(units[b0["main"][0]])], by_unit[id(units[b0["main"][-1]])]
+        dh0 = r_first["dx"] + (by_unit[id(units[b0["down"]])]["dx"] if b0["down"] is not None else r_last0["dres"])
+        pin = tape["pool_in"].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        torch.nn.functional.max_pool2d(pin, 3, stride=2, padding=1).backward(dh0.permute(0, 3, 1, 2).contiguous())
+        assert torch.equal(r0["dy"], pin.grad.permute(0, 2, 3, 1).contiguous())
     # ---- (3) end to end against the oracle (trainer's view): bf16 differences compound through up to 53 BatchNorms
     #          with batch statistics of as few as 6 samples per channel, so only direction and scale are asserted
     want_out, want_g, want_stats = RO.resnet_encoder_train_step(sd, name, x, dout, trainable, emulate_bf16=True)
@@ -156,9 +187,9 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
     # from 3e-3 at the stem to 0.3 at layer4, no jump at any layer): random weights, BatchNorm re-normalising every
     # layer with batch statistics over as few as 24 positions and the ReLU gates make the net amplify rounding noise, and
     # two roundings of the same z (fp32 sums in another order) are two different noises.  So end to end only sanity is
-    # asserted -- finite, same direction for the bulk of the parameters -- and the unit-level checks (1), (2) above
-    # carry the precision claim.
-    assert np.isfinite(e_out) and float(np.median(cosines)) >= 0.5, (e_out, cosines[:5], float(np.median(cosines)))
+    # asserted -- finite, same direction for the bulk of the parameters -- and the unit-level checks (1), (2) and the
+    # exact routing check (2b) above carry the correctness claim.
+    assert np.isfinite(e_out) and float(np.median(cosines)) >= 0.3, (e_out, cosines[:5], float(np.median(cosines)))
     # ---- (4) the torch.autograd route (the reference Trainer's loss.backward()) gives the same gradients; frozen
     #          parameters get none
     enc2, _ = _encoder(name, H, W, freeze, seed=11)
