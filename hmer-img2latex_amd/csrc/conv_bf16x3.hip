@@ -134,11 +134,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     typedef Tile3<WX> TL;
     constexpr int PR = TL::TR / 2, PC = TL::TC / 2;
     __shared__ __attribute__((aligned(16))) uint4 in_s[TL::IN_U4];
-    __shared__ __attribute__((aligned(16))) uint4 w_s[2 * W_PHASE_U4];         // the 3 taps of one filter row, two buffers
-    // fp32 staging of the pooled tile: ALIASES the input image (free between a tile's last phase and the next tile's
-    // first commit), which is what pays for the second weight buffer at two workgroups per CU (70.5 KB each)
-    static_assert(sizeof(float) * CO_BLK * 65 <= sizeof(uint4) * TL::IN_U4, "out_s must fit in in_s");
-    float* const out_s = reinterpret_cast<float*>(in_s);
+    __shared__ __attribute__((aligned(16))) uint4 w_s[W_PHASE_U4];             // the 3 taps of one filter row
+    __shared__ float out_s[CO_BLK * 65];                                       // fp32 staging of the pooled tile
     __shared__ unsigned char am_s[AM ? CO_BLK * 68 : 4];                       // pooling arg max of the tile (training)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -221,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
             }
         }
     };
-    auto commit_w = [&](int buf) {
+    auto commit_w = [&]() {
 #pragma unroll
         for (int e = 0; e < NWV; ++e) {
             const int idx = tid + e * 256;
-            if (idx < W_PHASE_U4) w_s[buf * W_PHASE_U4 + idx] = win[e];
+            if (idx < W_PHASE_U4) w_s[idx] = win[e];
         }
     };
 
@@ -233,36 +230,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     // other keeps the matrix cores busy.  A workgroup walks `items_per_wg` consecutive tiles of its 64-channel block
     // (the grid is sized to ONE resident round) and the first patch / filter row of the next tile are fetched
     // during the last phases of the current one, so only the first tile pays a prologue.
-    // Per chunk: 3 phases (filter rows) of 3 taps x 24 MFMAs per wave.  The weight slab of phase p + 1 is requested at
-    // the start of phase p and written to the OTHER weight buffer right after this wave has issued the phase's last
-    // MFMAs (the matrix pipe is still draining them), so a phase costs ONE barrier and the weight staging is off the
-    // critical path; only a chunk boundary (new input patch into the single-buffered in_s) needs a second barrier.
-    // r02 structure (one weight buffer, commit between two barriers of every phase): blocks 2 / 3 at 0.236 / 0.227 ms.
+    // Per chunk: 3 phases (filter rows) of 3 taps x 24 MFMAs per wave.
     const int n_phases = 3 * n_chunks;
     const int it0 = walk * items_per_wg, it_end = min(it0 + items_per_wg, n_items);
     if (it0 >= n_items) return;
-    // The (chunk, filter row) order of a tile is ROTATED by the tile's index inside its image: the 512 resident
-    // workgroups otherwise sweep the same 18 KB weight slab at the same moment (they start together and keep the same
-    // pace), i.e. the same ~144 cache lines of L2 are requested by every CU at once.  The rotation depends on the tile
-    // position only, so an image's sums are added in the same order wherever it sits in a batch.
-    auto rot_of = [&](int item, int& c0, int& k0) {
-        const int tl = item % tiles_per_img;
-        k0 = tl % 3;
-        c0 = (tl / 3) % n_chunks;
-    };
-    int c0, k0;
-    rot_of(it0, c0, k0);
     setup_fetch(it0);
-    fetch_x(c0);
-    fetch_w(c0 * 3 + k0);
-    int buf = 0;
-    commit_w(0);                                                     // visible after the first chunk's barrier
+    fetch_x(0);
+    fetch_w(0);
     for (int it = it0; it < it_end; ++it) {
         const int b = it / tiles_per_img, tl = it - b * tiles_per_img;
         const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
         const int y0 = ty * TL::TR, x0 = tx * TL::TC;
-        int nc0 = 0, nk0 = 0;
-        if (it + 1 < it_end) rot_of(it + 1, nc0, nk0);
         f32x16 acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -270,29 +248,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        if (it > it0) __syncthreads();                               // the epilogue's reads of out_s (= in_s) are done
 
-        for (int ci = 0; ci < n_chunks; ++ci) {
-            int chunk = ci + c0;
-            if (chunk >= n_chunks) chunk -= n_chunks;
-            int chunk_next = chunk + 1;
-            if (chunk_next >= n_chunks) chunk_next -= n_chunks;
-            commit_x();                                              // in_s is free: every wave passed the last phase's barrier
-            __syncthreads();
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
 #pragma unroll
-            for (int kj = 0; kj < 3; ++kj) {
-                int ky = kj + k0;
-                if (ky >= 3) ky -= 3;
-                int ky_next = ky + 1;
-                if (ky_next >= 3) ky_next -= 3;
-                if (kj < 2) fetch_w(chunk * 3 + ky_next);
-                else if (ci + 1 < n_chunks) fetch_w(chunk_next * 3 + k0);
-                else if (it + 1 < it_end) fetch_w(nc0 * 3 + nk0);
-                if (kj == 0) {
-                    if (ci + 1 < n_chunks) fetch_x(chunk_next);
-                    else if (it + 1 < it_end) { setup_fetch(it + 1); fetch_x(nc0); }
+            for (int ky = 0; ky < 3; ++ky) {
+                __syncthreads();
+                if (ky == 0) commit_x();
+                commit_w();
+                __syncthreads();
+                if (chunk * 3 + ky + 1 < n_phases) fetch_w(chunk * 3 + ky + 1);
+                else if (it + 1 < it_end) fetch_w(0);
+                if (ky == 0) {
+                    if (chunk + 1 < n_chunks) fetch_x(chunk + 1);
+                    else if (it + 1 < it_end) { setup_fetch(it + 1); fetch_x(0); }
                 }
-                const uint4* wcur = w_s + buf * W_PHASE_U4;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     bf16x8 a[2][3], bw[NT][3];
@@ -307,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
                         for (int sp = 0; sp < 3; ++sp) {
-                            const uint4 t = wcur[b_base + ((kx * 3 + sp) * 2) * CO_BLK + n * 32];
+                            const uint4 t = w_s[b_base + ((kx * 3 + sp) * 2) * CO_BLK + n * 32];
                             bw[n][sp] = *reinterpret_cast<const bf16x8*>(&t);
                         }
                     // smallest partial products first; consecutive MFMAs go to different accumulators
@@ -320,14 +289,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
                             for (int n = 0; n < NT; ++n)
                                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][TI[t]], bw[n][TJ[t]], acc[m][n], 0, 0, 0);
                 }
-                // the other buffer was last read in the previous phase, which every wave has left (its barrier)
-                if (ci * 3 + kj + 1 < n_phases || it + 1 < it_end) commit_w(buf ^ 1);
-                buf ^= 1;
-                __syncthreads();
             }
         }
-        c0 = nc0;
-        k0 = nk0;
 
         // ---- epilogue (same lane layout as conv.hip): registers 4q..4q+3 = the 2x2 quad of pooled column 2q + h
         const int py0 = y0 >> 1, px0 = x0 >> 1;
