@@ -36,9 +36,14 @@ constexpr int GRP_STAT_FAILED = 0, GRP_STAT_GROUPS = 1, GRP_STAT_LOCAL = 2;
 // local == false: sc1 store (write-through to memory, seen from every XCD).  local == true (all four members were
 // found on ONE XCD): sc0 store, the line stays in that XCD's L2 where the peers' sc1 loads (L1 bypassed) find it --
 // an L2 round trip instead of a memory one.
+// The L2-local flavour rests on gfx950's write-through L1 (a workgroup-scope store still reaches the XCD's L2, where the
+// peers' L1-bypassing polls find it), NOT on the HSA memory model: it is compiled for gfx950 only; any other target gets
+// the conformant agent-scope store whatever the caller measured.
 __device__ __forceinline__ void store_granule(u64_t* g, u64_t v, bool local) {
-    if (local) __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(__gfx950__)
+    if (local) { __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+#endif
+    __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64_t granule(unsigned tag, float v) { return ((u64_t)tag << 32) | (u64_t)__float_as_uint(v); }
 __device__ __forceinline__ u64_t load_granule(const u64_t* g) {

@@ -709,7 +709,9 @@ int ring_depth(int kt, long tiles, int flags) {
 template <int NTW, int BK, int NS, bool CONV, bool RES>
 int launch_ring4(const BfGemm& g, int nb_n, int total, hipStream_t s) {
     constexpr int lds = NS * (GM + 64 * NTW) * BK * 2;
-    const hipError_t attr =
+    // once per template instantiation (a function-local static is initialised exactly once, thread-safe): the attribute
+    // is a property of the kernel, not of the launch -- r02 asked the runtime again on each of the 53 launches per image batch
+    static const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return I2L_ERR_LAUNCH;
