@@ -59,11 +59,24 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
         const int row = (int)(idx / pl.new_w), xx = (int)(idx - (long)row * pl.new_w);
         const int xmin = bh[2 * xx], n = bh[2 * xx + 1];
         const int32_t* k = kh + (size_t)xx * pl.kh_ksize;
-        for (int c = 0; c < out_c; ++c) {
-            int acc = 1 << (PREC - 1);
-            for (int x = 0; x < n; ++x) acc += src_px(img, pl.src_w, pl.src_c, out_c, pl.ybox_first + row, xmin + x, c) * k[x];
-            tmp[((size_t)row * pl.new_w + xx) * out_c + c] = (uint8_t)clip8(acc);
+        // one pass over the taps for all bands: a source pixel (and its mode conversion) is read once, not once per band
+        int acc0 = 1 << (PREC - 1), acc1 = acc0, acc2 = acc0;
+        const uint8_t* srow = img + ((size_t)(pl.ybox_first + row) * pl.src_w + xmin) * pl.src_c;
+        if (pl.src_c == 1) {                                   // L source: the bands of an RGB output are equal
+            for (int x = 0; x < n; ++x) acc0 += srow[x] * k[x];
+            acc1 = acc2 = acc0;
+        } else if (out_c == 1) {                               // RGB -> L (Convert.c rgb2l)
+            for (int x = 0; x < n; ++x)
+                acc0 += ((srow[3 * x] * 19595 + srow[3 * x + 1] * 38470 + srow[3 * x + 2] * 7471 + 0x8000) >> 16) * k[x];
+        } else {
+            for (int x = 0; x < n; ++x) {
+                const int kx = k[x];
+                acc0 += srow[3 * x] * kx; acc1 += srow[3 * x + 1] * kx; acc2 += srow[3 * x + 2] * kx;
+            }
         }
+        uint8_t* o = tmp + ((size_t)row * pl.new_w + xx) * out_c;
+        o[0] = (uint8_t)clip8(acc0);
+        if (out_c == 3) { o[1] = (uint8_t)clip8(acc1); o[2] = (uint8_t)clip8(acc2); }
     }
 }
 
@@ -82,23 +95,32 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)out_h * out_w; idx += (long)gridDim.x * 256) {
         const int y = (int)(idx / out_w), x = (int)(idx - (long)y * out_w);
         const int xs = x + left;
-        for (int c = 0; c < out_c; ++c) {
-            int v;
-            if (xs >= pl.new_w) {
-                v = (out_c == 1 || c == 0) ? 255 : 0;      // Image.new(mode, size, 255): white for L, (255,0,0) for RGB
-            } else if (pl.need_v) {
-                const int y0 = bv[2 * y] - (pl.need_h ? pl.ybox_first : 0), n = bv[2 * y + 1];   // Resample.c "shift bounds for vertical pass"
-                const int32_t* k = kv + (size_t)y * pl.kv_ksize;
-                int acc = 1 << (PREC - 1);
-                if (pl.need_h)
-                    for (int j = 0; j < n; ++j) acc += tmp[((size_t)(y0 + j) * pl.new_w + xs) * out_c + c] * k[j];
-                else
-                    for (int j = 0; j < n; ++j) acc += src_px(img, pl.src_w, pl.src_c, out_c, y0 + j, xs, c) * k[j];
-                v = clip8(acc);
+        int v[3];
+        if (xs >= pl.new_w) {
+            v[0] = 255; v[1] = v[2] = (out_c == 1) ? 255 : 0;     // Image.new(mode, size, 255): white for L, (255,0,0) for RGB
+        } else if (pl.need_v) {
+            const int y0 = bv[2 * y] - (pl.need_h ? pl.ybox_first : 0), n = bv[2 * y + 1];   // Resample.c "shift bounds for vertical pass"
+            const int32_t* k = kv + (size_t)y * pl.kv_ksize;
+            int a0 = 1 << (PREC - 1), a1 = a0, a2 = a0;
+            if (pl.need_h) {
+                const uint8_t* col = tmp + ((size_t)y0 * pl.new_w + xs) * out_c;
+                const size_t rs = (size_t)pl.new_w * out_c;
+                if (out_c == 1) for (int j = 0; j < n; ++j) a0 += col[j * rs] * k[j];
+                else for (int j = 0; j < n; ++j) { const int kj = k[j]; a0 += col[j * rs] * kj; a1 += col[j * rs + 1] * kj; a2 += col[j * rs + 2] * kj; }
             } else {
-                v = pl.need_h ? tmp[((size_t)y * pl.new_w + xs) * out_c + c] : src_px(img, pl.src_w, pl.src_c, out_c, y, xs, c);
+                for (int j = 0; j < n; ++j) {
+                    const int kj = k[j];
+                    a0 += src_px(img, pl.src_w, pl.src_c, out_c, y0 + j, xs, 0) * kj;
+                    if (out_c == 3) { a1 += src_px(img, pl.src_w, pl.src_c, out_c, y0 + j, xs, 1) * kj; a2 += src_px(img, pl.src_w, pl.src_c, out_c, y0 + j, xs, 2) * kj; }
+                }
             }
-            float t = __fdiv_rn((float)v, 255.0f);                          // utils.py:68
+            v[0] = clip8(a0); v[1] = clip8(a1); v[2] = clip8(a2);
+        } else {
+            for (int c = 0; c < out_c; ++c)
+                v[c] = pl.need_h ? tmp[((size_t)y * pl.new_w + xs) * out_c + c] : src_px(img, pl.src_w, pl.src_c, out_c, y, xs, c);
+        }
+        for (int c = 0; c < out_c; ++c) {
+            float t = __fdiv_rn((float)v[c], 255.0f);                       // utils.py:68
             if (normalize) {
                 if (out_c == 1 || normalize == 2) t = __fsub_rn(__fmul_rn(t, 2.0f), 1.0f);   // utils.py:74; predictor.py:449-451
                 else t = __fdiv_rn(__fsub_rn(t, mean[c]), stdv[c]);         // utils.py:77-79
