@@ -221,13 +221,13 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NTW, int BK, int NS, bool CONV, bool RES>
-__global__ __launch_bounds__(256) void gemm_bf16_ring_kernel(BfGemm g, int nb_n, int total_tiles) {
+template <int NTW, int BK, int NS, bool CONV, bool RES, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void gemm_bf16_ring_kernel(BfGemm g, int nb_n, int total_tiles) {
     constexpr int BN = 64 * NTW, CH = BK / 8, ROWB = BK * 2;
     constexpr int A_BYTES = GM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
     constexpr int NLA = A_BYTES / 4096, NLW = W_BYTES / 4096, NL = NLA + NLW;   // loads per thread per stage
     constexpr int CLD = BN + 8, CHUNKS = BN / 8, NRES = GM * CHUNKS / 256;
-    static_assert(NS >= 2 && NS <= 4 && NL * (NS - 2) < 64, "ring depth");
+    static_assert(NS >= 1 && NS <= 4 && (NS < 2 || NL * (NS - 2) < 64), "ring depth");   // NS == 1: a single K tile (K == BK)
     static_assert(GM * CLD * 2 <= NS * STAGE, "staged C tile must fit in the ring");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_ring_kernel(BfGemm g, int nb_n,
 
     const int KT = g.K / BK;
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
+    for (int s = 0; s < (NS > 1 ? NS - 1 : 1); ++s)
         if (s < KT) issue();
     int slot = 0;
     for (int kt = 0; kt < KT; ++kt) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_ring_kernel(BfGemm g, int nb_n,
             for (int x = 0; x < NTW; ++x)
                 b[ks][x] = *reinterpret_cast<const bf16x8*>(st + offB[x] + (((2 * ks) ^ qB[x]) << 4));
         }
-        if (kt + NS - 1 < KT) issue();
+        if (NS > 1 && kt + NS - 1 < KT) issue();
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
@@ -706,16 +706,16 @@ int ring_depth(int kt, long tiles, int flags) {
     if (forced >= 2 && forced <= 4) return forced;
     return (tiles <= 256 && kt >= 4) ? 4 : 2;
 }
-template <int NTW, int BK, int NS, bool CONV, bool RES>
+template <int NTW, int BK, int NS, bool CONV, bool RES, int OCC = 1>
 int launch_ring4(const BfGemm& g, int nb_n, int total, hipStream_t s) {
     constexpr int lds = NS * (GM + 64 * NTW) * BK * 2;
     // once per template instantiation (a function-local static is initialised exactly once, thread-safe): the attribute
     // is a property of the kernel, not of the launch -- r02 asked the runtime again on each of the 53 launches per image batch
     static const hipError_t attr =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES, OCC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return I2L_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES>), dim3(total), dim3(256), lds, s, g, nb_n, total);
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES, OCC>), dim3(total), dim3(256), lds, s, g, nb_n, total);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }
@@ -832,12 +832,21 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     g.res = static_cast<const bf16_t*>(residual); g.ldr = Cout;
     g.C = static_cast<bf16_t*>(y); g.ldc = Cout;
     g.M = (int)M; g.N = Cout; g.K = Kp; g.relu = relu;
-    const int gn = Cout <= 64 ? 64 : 128;                  // narrow tile for the 64-channel layers (no wasted MFMAs)
+    // short reductions (K <= 128: the 1x1 convs of layer1 / layer2 that expand 64 / 128 channels) are bound by HBM, not by
+    // the matrix cores: 64-column tiles at THREE workgroups per CU (48 KB of LDS, <= 168 registers) keep more bytes in flight
+    const bool short_k = direct && Kp <= 256 && !((flags >> 8) & 0xF) && (long)i2l_cdiv((int)M, GM) * i2l_cdiv(Cout, 64) >= 1024;
+    const int gn = (Cout <= 64 || short_k) ? 64 : 128;     // narrow tile for the 64-channel layers (no wasted MFMAs)
     if (!(flags & I2L_FLAG_RESNET_NO_RING) && (direct || implicit) && Kp % 64 == 0) {
         const int nb_n = i2l_cdiv(Cout, gn), nb_m = i2l_cdiv((int)M, GM);
         const long total = (long)nb_n * nb_m;
         const int depth = ring_depth(Kp / 64, total, flags);
         if (total > 0x7fffffff) return I2L_ERR_UNSUPPORTED;
+        if (short_k && Kp == 64)          // one K tile: no ring at all, 24.5 KB of LDS, four workgroups per CU
+            return g.res ? launch_ring4<1, 64, 1, false, true, 4>(g, nb_n, (int)total, s)
+                         : launch_ring4<1, 64, 1, false, false, 4>(g, nb_n, (int)total, s);
+        if (short_k)
+            return g.res ? launch_ring4<1, 64, 2, false, true, 3>(g, nb_n, (int)total, s)
+                         : launch_ring4<1, 64, 2, false, false, 3>(g, nb_n, (int)total, s);
         return gn == 64 ? launch_ring<1>(g, depth, nb_n, (int)total, s) : launch_ring<2>(g, depth, nb_n, (int)total, s);
     }
     dim3 grid(i2l_cdiv(Cout, gn), i2l_cdiv((int)M, GM));
