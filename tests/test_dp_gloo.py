@@ -124,3 +124,27 @@ def test_two_piece_allreduce_is_bit_identical_to_one():
     out = mgr.dict()
     mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert out["two_piece_equals_single"] and out["finish_only_equals_single"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_card_rehearsal():
+    """`python bench.py --gpus 2` with no launcher around it (the self-launch path) as a one-card rehearsal: two ranks
+    over gloo share the GPU, rank 0 prints ONE line with n_gpus = 2 and twice the per-rank batch; the train mode's line
+    carries the all-reduce timing fields.  (RCCL needs one GPU per rank: the driver's multi-GPU run is the real thing.)"""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["I2L_DIST_BACKEND"] = "gloo"
+    for mode, keys in (("greedy", ()), ("train", ("all_reduce_ms", "all_reduce_busbw_gbs", "all_reduce_payload_mb"))):
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                            "--mode", mode, "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+        assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"]
+        for k in keys:
+            assert k in d["config"], k
