@@ -577,9 +577,12 @@ def test_bf16_conv_bn_act_vs_torch(case):
         assert float(((o - outs[0]).abs() - 2.0 ** -7 * outs[0].abs()).max()) <= 1e-3
 
 
-@pytest.mark.parametrize("model_name,hw", [("resnet18", (32, 64)), ("resnet50", (64, 96))])
+@pytest.mark.parametrize("model_name,hw", [("resnet18", (32, 64)), ("resnet50", (64, 96)), ("resnet34", (32, 64)),
+                                           ("resnet101", (32, 96)), ("resnet152", (32, 64))])
 def test_resnet_encoder_vs_oracle(model_name, hw):
-    """bf16 MFMA trunk against the fp32 restatement (parity unpinned: no reference output exists)."""
+    """bf16 MFMA trunk against the fp32 restatement (parity unpinned: no reference output exists), every model name
+    the reference accepts (encoder.py:185-196).  The deeper variants compound bf16 rounding over up to 152 layers:
+    their tolerance scales with depth."""
     import resnet_oracle as RO
     from img2latex_amd.model import ResNetEncoder
     enc = ResNetEncoder(hw[0], hw[1], 3, model_name=model_name, embedding_dim=64)
@@ -596,8 +599,11 @@ def test_resnet_encoder_vs_oracle(model_name, hw):
         got = enc(x.to(DEV)).cpu()
     assert got.shape == (3, 64)
     # bf16 activations through 18-50 layers: a few 1e-2 relative to the feature scale
-    assert float((got_feat - want_feat).abs().max()) <= 4e-2 * float(want_feat.abs().max())
-    assert float((got - want).abs().max()) <= 4e-2 * max(1.0, float(want.abs().max()))
+    tol = {"resnet101": 8e-2, "resnet152": 1.2e-1}.get(model_name, 4e-2)
+    e_feat = float((got_feat - want_feat).abs().max()) / float(want_feat.abs().max())
+    e_out = float((got - want).abs().max()) / max(1.0, float(want.abs().max()))
+    record(f"{model_name} {hw[0]}x{hw[1]} trunk features vs fp32 oracle [rel to max]", e_feat)
+    assert e_feat <= tol and e_out <= tol, (e_feat, e_out)
     enc.train()                                       # training mode: batch statistics (tests/test_resnet_training.py)
     with torch.no_grad():
         tr = enc(x.to(DEV))
