@@ -581,8 +581,7 @@ def test_bf16_conv_bn_act_vs_torch(case):
                                            ("resnet101", (32, 96)), ("resnet152", (32, 64))])
 def test_resnet_encoder_vs_oracle(model_name, hw):
     """bf16 MFMA trunk against the fp32 restatement (parity unpinned: no reference output exists), every model name
-    the reference accepts (encoder.py:185-196).  The deeper variants compound bf16 rounding over up to 152 layers:
-    their tolerance scales with depth."""
+    the reference accepts (encoder.py:185-196); measured 6e-3 .. 1.1e-2 of the feature maximum."""
     import resnet_oracle as RO
     from img2latex_amd.model import ResNetEncoder
     enc = ResNetEncoder(hw[0], hw[1], 3, model_name=model_name, embedding_dim=64)
@@ -599,7 +598,7 @@ def test_resnet_encoder_vs_oracle(model_name, hw):
         got = enc(x.to(DEV)).cpu()
     assert got.shape == (3, 64)
     # bf16 activations through 18-50 layers: a few 1e-2 relative to the feature scale
-    tol = {"resnet101": 8e-2, "resnet152": 1.2e-1}.get(model_name, 4e-2)
+    tol = 4e-2
     e_feat = float((got_feat - want_feat).abs().max()) / float(want_feat.abs().max())
     e_out = float((got - want).abs().max()) / max(1.0, float(want.abs().max()))
     record(f"{model_name} {hw[0]}x{hw[1]} trunk features vs fp32 oracle [rel to max]", e_feat)
