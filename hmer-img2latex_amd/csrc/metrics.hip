@@ -91,6 +91,117 @@ __global__ __launch_bounds__(MT) void sequence_metrics_kernel(const int32_t* __r
     if (tid < 2 && tla_out) tla_out[(size_t)pair * 2 + tid] = cnt[4 + tid];
 }
 
+// The same statistics with the Levenshtein distance from Myers' bit-vector algorithm (block formulation, J. ACM 46(3)
+// 1999; global-distance boundary as in Hyyro 2003) instead of the anti-diagonal table walk: the reference's recurrence
+// (metrics.py:73-81: equal tokens copy the diagonal, otherwise 1 + min of the three neighbours) IS the Levenshtein
+// recurrence, so the table corner is the edit distance and any exact algorithm gives the same integer.  Wave 0 owns the
+// distance: the prediction's tokens sit in registers (lane = position within a 64-token block, W blocks), and per
+// target token a ballot yields the match mask of a block, which ~20 scalar bit operations turn into the block's new
+// vertical delta vectors and its horizontal carry into the next block -- C x W short dependent steps instead of R + C
+// workgroup barriers (150 x 150 tokens: ~30 us instead of ~300).  Waves 1-3 count the n-gram matches and the accuracy
+// meanwhile.  W <= 4 (sequences up to 256 tokens); longer ones take the table kernel above.
+template <int W>
+__global__ __launch_bounds__(MT) void sequence_metrics_bp_kernel(const int32_t* __restrict__ pred, const int32_t* __restrict__ pred_len,
+                                                                 int pred_stride, const int32_t* __restrict__ tgt,
+                                                                 const int32_t* __restrict__ tgt_len, int tgt_stride, int max_len,
+                                                                 int max_n, int pad_id, int32_t* __restrict__ lev_out,
+                                                                 int32_t* __restrict__ match_out, int32_t* __restrict__ tla_out) {
+    typedef unsigned long long u64;
+    extern __shared__ int sm[];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = min(max(pred_len[pair], 0), max_len), C = min(max(tgt_len[pair], 0), max_len);
+    int* a = sm;
+    int* b = a + max_len;
+    int* cnt = b + max_len;
+    for (int i = tid; i < R; i += MT) a[i] = pred[(size_t)pair * pred_stride + i];
+    for (int i = tid; i < C; i += MT) b[i] = tgt[(size_t)pair * tgt_stride + i];
+    if (tid < 6) cnt[tid] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        int score = R;
+        if (R == 0) score = C;
+        else if (C > 0) {
+            int pa[W];
+            bool ok[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                ok[w] = 64 * w + lane < R;
+                pa[w] = ok[w] ? a[64 * w + lane] : 0;
+            }
+            u64 Pv[W], Mv[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) { Pv[w] = ~0ull; Mv[w] = 0ull; }
+            const int last = (R - 1) >> 6;
+            const u64 high = 1ull << ((R - 1) & 63);
+            for (int j = 0; j < C; ++j) {
+                const int t = b[j];
+                int hin = 1;                                    // D[0][j] - D[0][j-1] = +1: global distance
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (w <= last) {
+                        u64 Eq = __ballot(ok[w] && pa[w] == t);
+                        const u64 pv = Pv[w], mv = Mv[w];
+                        const u64 Xv = Eq | mv;
+                        if (hin < 0) Eq |= 1ull;
+                        const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                        u64 Ph = mv | ~(Xh | pv);
+                        u64 Mh = pv & Xh;
+                        const u64 hb = w == last ? high : (1ull << 63);
+                        const int hout = (Ph & hb) ? 1 : ((Mh & hb) ? -1 : 0);
+                        Ph <<= 1;
+                        Mh <<= 1;
+                        if (hin < 0) Mh |= 1ull;
+                        else if (hin > 0) Ph |= 1ull;
+                        Pv[w] = Mh | ~(Xv | Ph);
+                        Mv[w] = Ph & Xv;
+                        hin = hout;
+                    }
+                }
+                score += hin;                                   // D[R][j+1] - D[R][j]
+            }
+        }
+        if (lane == 0) lev_out[pair] = score;
+    } else {
+        const int t3 = tid - 64, NT3 = MT - 64;
+        for (int g = 1; g <= max_n; ++g) {
+            const int ng = R - g + 1, nt = C - g + 1;
+            int local = 0;
+            if (ng > 0 && nt > 0) {
+                for (int i = t3; i < ng; i += NT3) {
+                    bool first = true;
+                    int cg = 0, ct = 0;
+                    for (int j = 0; j < ng; ++j) {
+                        bool eq = true;
+                        for (int k = 0; k < g; ++k) eq = eq && a[j + k] == a[i + k];
+                        cg += eq ? 1 : 0;
+                        if (eq && j < i) first = false;
+                    }
+                    for (int j = 0; j < nt; ++j) {
+                        bool eq = true;
+                        for (int k = 0; k < g; ++k) eq = eq && b[j + k] == a[i + k];
+                        ct += eq ? 1 : 0;
+                    }
+                    if (first) local += min(cg, ct);
+                }
+            }
+            if (local) atomicAdd(&cnt[g - 1], local);
+        }
+        const int ml = min(R, C);
+        int correct = 0, nonpad = 0;
+        for (int i = t3; i < ml; i += NT3) {
+            const bool np = b[i] != pad_id;
+            nonpad += np ? 1 : 0;
+            correct += (np && a[i] == b[i]) ? 1 : 0;
+        }
+        if (correct) atomicAdd(&cnt[4], correct);
+        if (nonpad) atomicAdd(&cnt[5], nonpad);
+    }
+    __syncthreads();
+    if (tid < 4) match_out[(size_t)pair * 4 + tid] = tid < max_n ? cnt[tid] : 0;
+    if (tid < 2 && tla_out) tla_out[(size_t)pair * 2 + tid] = cnt[4 + tid];
+}
+
 // masked_accuracy (metrics.py:226-238): one wave per row: first-index arg max over V, compare, mask; integer counts.
 __global__ __launch_bounds__(MT) void masked_accuracy_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                              long rows, int V, long pad_id,
@@ -171,6 +282,17 @@ extern "C" int i2l_sequence_metrics(const int32_t* pred, const int32_t* pred_len
     if (!pred || !pred_len || !target || !target_len || !lev_out || !match_out || pairs <= 0 || max_len < 0 || max_n < 1 ||
         max_n > 4 || pred_stride < max_len || target_stride < max_len)
         return I2L_ERR_ARG;
+    if (max_len <= 256) {                                   // bit-vector Levenshtein: W = ceil(max_len / 64) blocks
+        const size_t lds_bp = ((size_t)2 * max_len + 8) * sizeof(int);
+        const int Wb = max_len <= 64 ? 1 : (max_len <= 128 ? 2 : (max_len <= 192 ? 3 : 4));
+        hipStream_t sb = i2l_s(stream);
+#define I2L_BP(W_) hipLaunchKernelGGL(sequence_metrics_bp_kernel<W_>, dim3(pairs), dim3(MT), lds_bp, sb, pred, pred_len, pred_stride, \
+                                      target, target_len, target_stride, max_len, max_n, pad_id, lev_out, match_out, tla_out)
+        if (Wb == 1) I2L_BP(1); else if (Wb == 2) I2L_BP(2); else if (Wb == 3) I2L_BP(3); else I2L_BP(4);
+#undef I2L_BP
+        I2L_CHECK_LAUNCH();
+        return I2L_OK;
+    }
     const size_t lds = metrics_lds(max_len);
     if (lds > 160 * 1024) return I2L_ERR_UNSUPPORTED;       // sequences longer than ~8k tokens
     if (lds > 64 * 1024 &&

@@ -131,3 +131,32 @@ def test_very_long_sequences():
         p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
         assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), i
         assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [1, 63, 64, 65, 128, 150, 192, 193, 256])
+def test_bit_vector_levenshtein_block_boundaries(width):
+    """max_len <= 256 takes the bit-vector kernel (Myers' block algorithm, one 64-token block per word): every block
+    count, lengths on and around the block boundaries, tiny and large alphabets (match masks dense / sparse), one side
+    empty, identical and disjoint pairs -- the same integers as the oracle's table walk (metrics.py:63-83)."""
+    from img2latex_amd.training import metrics as M
+    dev = torch.device("cuda:0")
+    B = 24
+    lens = sorted({0, 1, 2, width // 2, max(width - 1, 0), width, min(63, width), min(64, width), min(65, width),
+                   min(127, width), min(129, width)})
+    for alpha in (2, 5, 400):
+        P = synth.randint(100 + width, f"p{alpha}", (B, width), 1, 1 + alpha).astype(np.int32)
+        T = synth.randint(200 + width, f"t{alpha}", (B, width), 1, 1 + alpha).astype(np.int32)
+        T[3] = P[3]                                              # identical pair
+        T[4] = P[4] + 1000                                       # no token in common
+        T[5, : width // 2] = P[5, width - width // 2:]           # shifted overlap
+        pl = np.array([lens[i % len(lens)] for i in range(B)], np.int32)
+        tl = np.array([lens[(i * 7 + 3) % len(lens)] for i in range(B)], np.int32)
+        pl[3] = tl[3] = width
+        pl[4] = tl[4] = width
+        st = M.device_sequence_statistics(torch.from_numpy(P).to(dev), torch.from_numpy(pl).to(dev),
+                                          torch.from_numpy(T).to(dev), torch.from_numpy(tl).to(dev), 4, PAD, _max_len=width)
+        for i in range(B):
+            p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
+            assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), (width, alpha, i, pl[i], tl[i])
+            assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), (width, alpha, i)
