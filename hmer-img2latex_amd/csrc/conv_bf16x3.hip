@@ -634,7 +634,8 @@ int launch_fixup(const float* x, const float* w, const float* bias, float* y, un
 }  // namespace
 
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
-                        int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, int full) {
+                        int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, int full,
+                        int weights_packed) {
     if (full && ((H | W) & 1)) return I2L_ERR_UNSUPPORTED;       // full resolution is written quad by quad
     const size_t pack_bytes = i2l_conv_bf16x3_workspace_bytes(Cin, Cout);
     if (workspace_bytes < pack_bytes + (amax ? i2l_conv_fixlist_bytes() : 0) || !workspace) return I2L_ERR_WORKSPACE;
@@ -645,6 +646,9 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     if (Cout % CO_BLK != 0 && !(full && Cout == 32)) return I2L_ERR_UNSUPPORTED;
     bf16_t* wp = static_cast<bf16_t*>(workspace);
     const size_t total = (size_t)co_blocks * n_chunks * 9 * 2 * CO_BLK * 8;
+    // weights_packed (I2L_FLAG_WEIGHTS_PACKED, inference only): the caller kept this workspace since an earlier call with
+    // the same weights, whose packed image it still holds -- the weight-only work is not repeated per batch
+    if (!(weights_packed && !amax && !full))
     hipLaunchKernelGGL(conv_pack3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout,
                        n_chunks, total, full ? 1 : 0, fix);
     I2L_CHECK_LAUNCH();

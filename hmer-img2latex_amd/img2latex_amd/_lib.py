@@ -22,6 +22,7 @@ PREP_WEIGHTS, PREP_ROWS, PREP_ALL = 1, 2, 3
 MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
 # kernel-selection flags (include/img2latex_hip.h I2L_FLAG_*): explicit arguments, the library reads no environment
 FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0x1, 0x2, 0x4, 0x8
+FLAG_WEIGHTS_PACKED = 0x10          # conv forward: the workspace still holds the packed filters of these weights
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
 FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks of the grouped kernels
 

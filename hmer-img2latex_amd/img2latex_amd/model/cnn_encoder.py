@@ -50,6 +50,7 @@ class CNNEncoder(nn.Module):
         self.embedding_layer = nn.Linear(self.flattened_size, embedding_dim)
         self.activation = nn.ReLU()
         self._ws: Optional[torch.Tensor] = None
+        self._packed_ws = {}       # block index -> (workspace holding the packed filters, key they were packed for)
         self.kernel_flags = 0      # _lib.FLAG_EXACT_FP32: exact fp32 kernels instead of the 3 x bf16 split
 
     def _workspace(self, nbytes: int, device) -> Optional[torch.Tensor]:
@@ -75,14 +76,26 @@ class CNNEncoder(nn.Module):
             wt = _lib.require_gpu(conv.weight.detach(), "conv weight")
             bs = _lib.require_gpu(conv.bias.detach(), "conv bias")
             nbytes = L.i2l_conv_workspace_bytes(cin, conv.out_channels)
-            ws = self._workspace(nbytes, x.device)
             amax = None
+            flags = self.kernel_flags
             if argmax_out is not None:
                 amax = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
                 argmax_out.append(amax)
+                ws = self._workspace(nbytes, x.device)
+            else:
+                # inference: every block keeps its own workspace, so the packed filter image written there survives from
+                # batch to batch; it is rebuilt only when the weight changed ((data_ptr, _version), as LSTMDecoder.prepare)
+                key = (wt.data_ptr(), conv.weight._version, x.device, nbytes, self.kernel_flags, _lib.stream_ptr())
+                held = self._packed_ws.get(i)
+                if held is None or held[0].numel() < max(nbytes, 16) or held[0].device != x.device:
+                    held = (torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device), None)
+                ws = held[0] if nbytes else None
+                if held[1] == key:
+                    flags |= _lib.FLAG_WEIGHTS_PACKED
+                self._packed_ws[i] = (held[0], key)
             _lib.check(L.i2l_conv3x3_relu_pool2_fwd(x.data_ptr(), wt.data_ptr(), bs.data_ptr(), y.data_ptr(),
                                                     _lib.ptr(amax), B, cin, h, w, conv.out_channels, _lib.ptr(ws),
-                                                    nbytes, self.kernel_flags, _lib.stream_ptr()),
+                                                    nbytes, flags, _lib.stream_ptr()),
                        "conv3x3_relu_pool2_fwd")
             _lib.mark(f"conv{i}")
             outs.append(y)

@@ -50,6 +50,10 @@ typedef void* i2l_stream_t;
                                           the grouped kernels (4 co-resident workgroups exchanging through L2)       */
 #define I2L_FLAG_RESNET_NO_RING 0x4    /* i2l_conv_bn_act_bf16_fwd: single-buffered GEMM instead of the LDS ring      */
 #define I2L_FLAG_RESNET_IM2COL_STEM 0x8 /* i2l_conv_bn_act_bf16_fwd: im2col image + GEMM instead of the fused stem    */
+#define I2L_FLAG_WEIGHTS_PACKED 0x10    /* i2l_conv3x3_relu_pool2_fwd without argmax_out: the workspace still holds the packed
+                                          (3 x bf16) filter image an EARLIER call wrote for the SAME weights -- the caller
+                                          kept the buffer and the weights have not changed -- so the weight-only packing
+                                          launch is skipped; ignored by the kernels that do not pack                 */
 #define I2L_FLAG_AGENT_SCOPE_EXCHANGE 0x20 /* grouped kernels (greedy, beam, training recurrences): every exchange store at
                                           agent scope (sc1, write-through) -- the HSA-memory-model-conformant flavour --
                                           even when the group's members share an XCD and the faster L2-local

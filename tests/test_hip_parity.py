@@ -940,3 +940,28 @@ def test_grouped_kernels_forced_timeout_fails_loudly_and_falls_back():
     mm.decoder.kernel_flags = 0
     out = ts.step(xs, forms)
     assert float(out["skipped"]) == 0.0 and np.isfinite(float(out["loss"]))
+
+
+def test_encoder_reuses_packed_filters_until_a_weight_changes():
+    """Inference keeps the packed (3 x bf16) filter images of conv blocks 2 / 3 from batch to batch
+    (I2L_FLAG_WEIGHTS_PACKED): a second batch gives what a fresh model gives, and an in-place weight update (version
+    bump) is picked up by the next call."""
+    d, cfg, sd_kw = load("primary")
+    m, _ = model_for("primary")
+    fresh = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+    fresh.load_state_dict(m.state_dict())
+    fresh = fresh.to(DEV).eval()
+    xa, xb = images(cfg, 5, seed=1, device=DEV), images(cfg, 5, seed=2, device=DEV)
+    with torch.no_grad():
+        m.encoder(xa)
+        got = m.encoder(xb)                                  # second call: packed filters reused
+        want = fresh.encoder(xb)                             # first call of another object: packs
+        assert torch.equal(got, want)
+        w = m.encoder.cnn_layers[3].weight
+        w.mul_(1.25)                                         # in place: same storage, new version
+        fresh.encoder.cnn_layers[3].weight.copy_(w)
+        fresh2 = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+        fresh2.load_state_dict(fresh.state_dict())
+        fresh2 = fresh2.to(DEV).eval()
+        assert torch.equal(m.encoder(xb), fresh2.encoder(xb))
+        w.div_(1.25)
