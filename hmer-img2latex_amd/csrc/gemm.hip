@@ -225,6 +225,11 @@ void plan(int M, int N, int K, int nz, int* ksplits, int* k_chunk) {
         const int max_s = K / 512;           // keep >= 512 of K per slice
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;
+    } else if (tiles <= 64 && K >= 256) {    // a quarter of the chip or less (the decoder's per-batch Genc GEMM: 64 tiles,
+        s = 256 / tiles;                     // K = 256): one 64-deep slice per workgroup fills it, the slab sum costs ~5 us
+        const int max_s = K / 64;
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
     }
     int kc = i2l_cdiv(i2l_cdiv(K, s), BK) * BK;
     s = i2l_cdiv(K, kc);
