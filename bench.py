@@ -146,18 +146,11 @@ def main():
 
     last = [ids_host]
 
-    down_s = torch.cuda.Stream(dev)          # the ids go home on their own stream: the 150 KB copy of batch i runs beside
-    decoded = torch.cuda.Event()             # the first conv block of batch i + 1 instead of in front of it
-
     def serial_step():
         with torch.no_grad():
             enc = model.encoder(images)
             ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
-            decoded.record()
-            with torch.cuda.stream(down_s):
-                down_s.wait_event(decoded)
-                ids_host.copy_(ids, non_blocking=True)
-                ids.record_stream(down_s)
+            ids_host.copy_(ids, non_blocking=True)
 
     def timed(step_fn, drain_fn, hooked):
         """W warmup steps, then exactly K steps between barrier + synchronize fences; returns seconds."""
