@@ -84,6 +84,9 @@ def main():
                     help="time the two-stream batch pipeline (encoder of batch i+1 beside the decode of batch i, "
                          "GreedyPipeline, row-per-workgroup decode kernel); a second, serial pass of the same number of "
                          "steps provides the undisturbed per-kernel times for the roofline object")
+    ap.add_argument("--dp-single-allreduce", action="store_true",
+                    help="--mode train: ONE all-reduce of the flat gradient buffer after the backward pass instead of the "
+                         "default two pieces (same sums), the first of which overlaps the conv backward")
     ap.add_argument("--launch-probe", action="store_true",
                     help="rendezvous check only (CPU, gloo): every rank all-reduces its rank number, rank 0 prints "
                          "{n_gpus, ranks_seen}; exercises the self-launch path of `--gpus N` without a GPU")
@@ -685,7 +688,7 @@ def extra_modes(args, world, rank, dev, dist):
         model.load_state_dict({k_: torch.from_numpy(v) for k_, v in synth.make_state_dict(cfg, seed=42).items()})
         model = model.to(dev).train()
         from img2latex_amd.training import TrainStep
-        ts = TrainStep(model, seed=1)
+        ts = TrainStep(model, seed=1, overlap_all_reduce=not args.dp_single_allreduce)
         images = torch.from_numpy(synth.make_images(Bt, cfg, seed=1234 + rank)).to(dev)
         forms = torch.from_numpy(synth.make_formulas(Bt, T, cfg["vocab_size"], seed=777 + rank)).to(torch.int32).to(dev)
 
@@ -715,7 +718,7 @@ def extra_modes(args, world, rank, dev, dist):
             return {"value": round(Bt * (T - 1) / min(ts_), 1), "unit": "tokens/s", "cores": torch.get_num_threads(),
                     "kind": "port", "sample": f"the full per-GPU workload (B={Bt}, T={T - 1}), autograd fwd+bwd+clip+Adam, "
                                               "dropout off, best of 2"}
-        name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "parallelism": f"dp{world}: one flat-buffer all-reduce"}
+        name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "parallelism": f"dp{world}: one flat-buffer all-reduce" + (" (single call)" if args.dp_single_allreduce else " (issued in two pieces, the first beside the conv backward)")}
 
     for _ in range(args.warmup):
         one_step()

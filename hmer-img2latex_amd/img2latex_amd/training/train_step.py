@@ -25,7 +25,7 @@ from .dp import OverlappedAllReduce, broadcast_parameters, rank_of
 class TrainStep:
     def __init__(self, model, lr: float = 1e-3, weight_decay: float = 1e-4, clip_grad_norm: float = 5.0,
                  pad_token_id: int = 0, label_smoothing: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, seed: int = 0):
+                 process_group=None, seed: int = 0, overlap_all_reduce: bool = True):
         self.model = model
         self.lr, self.weight_decay, self.clip = lr, weight_decay, clip_grad_norm
         self.pad, self.smoothing, self.betas, self.eps = pad_token_id, label_smoothing, betas, eps
@@ -70,6 +70,10 @@ class TrainStep:
                 p.data = view
                 self.grad_views[name] = self.flat_grads[o:o + p.numel()].view_as(p)
         broadcast_parameters(self.flat_params, 0, self.group)
+        # overlap_all_reduce=False: literally ONE all-reduce of the whole flat buffer after the backward pass (BASELINE
+        # north_star's wording); True (default): the same element-wise sums issued in two pieces, the first -- everything
+        # but the conv gradients -- as soon as the FC backward is enqueued, beside ~1 ms of conv backward (dp.py)
+        self.overlap_all_reduce = bool(overlap_all_reduce)
         self._reducer = OverlappedAllReduce(self.flat_grads, self.n_early, self.group)
         L = _lib.lib()
         # zeroed once: besides scratch it carries the count of skipped (non-finite) updates across calls
@@ -102,7 +106,8 @@ class TrainStep:
         denc = decoder_train_backward(model.decoder, dec_state, dlogits, dgr)
         egr = {n[len("encoder."):]: g for n, g in self.grad_views.items() if n.startswith("encoder.")}
         # decoder + FC gradients are final once the FC backward is enqueued: their all-reduce starts there
-        encoder_train_backward(model.encoder, enc_state, denc, egr, after_linear=self._reducer.start_early)
+        encoder_train_backward(model.encoder, enc_state, denc, egr,
+                               after_linear=self._reducer.start_early if self.overlap_all_reduce else None)
         return logits
 
     def apply(self) -> None:

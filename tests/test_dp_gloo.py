@@ -137,9 +137,10 @@ def test_bench_two_ranks_on_one_card_rehearsal():
     repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["I2L_DIST_BACKEND"] = "gloo"
-    for mode, keys in (("greedy", ()), ("train", ("all_reduce_ms", "all_reduce_busbw_gbs", "all_reduce_payload_mb"))):
+    ar = ("all_reduce_ms", "all_reduce_busbw_gbs", "all_reduce_payload_mb")
+    for mode, keys, extra in (("greedy", (), []), ("train", ar, []), ("train", ar, ["--dp-single-allreduce"])):
         r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                            "--mode", mode, "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                            "--mode", mode, "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, r.stdout[-2000:]
