@@ -656,7 +656,7 @@ extern "C" size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N) {
 extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                                         float* dw, float* db, int M, int K, int N, int relu, void* workspace,
                                         size_t workspace_bytes, int flags, i2l_stream_t stream) {
-    if (!x || !w || !dy || !dw || !db || (relu && !y) || M <= 0 || K <= 0 || N <= 0) return I2L_ERR_ARG;
+    if (!x || !w || !dy || !dw || (relu && !y) || M <= 0 || K <= 0 || N <= 0) return I2L_ERR_ARG;   // db may be NULL (no bias)
     if (!workspace || workspace_bytes < i2l_linear_bwd_workspace_bytes(M, K, N)) return I2L_ERR_WORKSPACE;
     hipStream_t s = i2l_s(stream);
     float* dpre = static_cast<float*>(workspace);
@@ -671,8 +671,10 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
         I2L_CHECK_LAUNCH();
         d = dpre;
     }
-    hipLaunchKernelGGL(colsum_small_kernel, dim3(i2l_cdiv(N, 32)), dim3(256), 0, s, d, M, N, db);
-    I2L_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3(i2l_cdiv(N, 32)), dim3(256), 0, s, d, M, N, db);
+        I2L_CHECK_LAUNCH();
+    }
     {   // dw[n][k] = sum_m d[m][n] * x[m][k]
         GemmArgs g = gemm_args();
         g.split_bf16 = (flags & I2L_FLAG_EXACT_FP32) ? 0 : 1;

@@ -313,12 +313,11 @@ class ResNetEncoder(nn.Module):
         _lib.check(L.i2l_im2col_f32(u["x"].data_ptr(), 2 if u["nchw"] else 0, B, H, W, Cin, k, k, s, pd, col.data_ptr(),
                                     _lib.stream_ptr()), "im2col_f32")
         dw = grads[name + ".weight"] if want_dw else torch.empty((co, Kc), dtype=torch.float32, device=dev)
-        db = torch.empty((co,), dtype=torch.float32, device=dev)
         dcol = torch.empty((M, Kc), dtype=torch.float32, device=dev) if need_dx else None
         nbytes = L.i2l_linear_bwd_workspace_bytes(M, Kc, co)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.check(L.i2l_linear_bias_act_bwd(col.data_ptr(), conv.weight.detach().data_ptr(), None, dz.data_ptr(),
-                                             _lib.ptr(dcol), dw.data_ptr(), db.data_ptr(), M, Kc, co, 0, ws.data_ptr(),
+                                             _lib.ptr(dcol), dw.data_ptr(), None, M, Kc, co, 0, ws.data_ptr(),
                                              nbytes, 0, _lib.stream_ptr()), "conv gradient GEMMs")
         if not need_dx:
             return None

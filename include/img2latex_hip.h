@@ -109,8 +109,9 @@ size_t i2l_linear_workspace_bytes(int M, int K, int N);
 int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, float* y,
                             int M, int K, int N, int relu, void* workspace, size_t workspace_bytes,
                             int flags, i2l_stream_t stream);
-/* Backward of the above: dy (M,N) -> dx (M,K) (or NULL), dw (N,K), db (N); with relu != 0 the
- * gradient is first masked by y > 0.  Gradients are overwritten. */
+/* Backward of the above: dy (M,N) -> dx (M,K) (or NULL), dw (N,K), db (N) (or NULL: a layer without bias, e.g. the
+ * ResNet convolutions that reach this entry through an im2col image); with relu != 0 the gradient is first masked by
+ * y > 0.  Gradients are overwritten. */
 size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N);
 int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                             float* dw, float* db, int M, int K, int N, int relu, void* workspace,
