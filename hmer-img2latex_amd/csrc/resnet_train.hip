@@ -26,7 +26,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 
-constexpr int SLAB_ROWS = 512;          // rows of the (M, C) matrix one workgroup reduces
+constexpr int SLAB_ROWS = 128;          // rows of the (M, C) matrix one workgroup reduces (M / 128 workgroups: 640+ at B = 64)
 
 // Per-channel partial sums over a slab of rows.  Thread = (row lane r of 256 / CG, channel group of 8 channels);
 // MODE 0: (sum z, sum z^2); MODE 1: (sum g, sum g * xhat) with g = dy masked by y > 0.
@@ -89,14 +89,31 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_t* __restric
     }
 }
 
+// sums of the slab partials of 32 channels per workgroup: thread = (channel c = tid & 31, slab lane tid >> 5), slabs
+// lane, lane + 8, ... added in double, the 8 lane sums in lane order (deterministic)
+__device__ __forceinline__ void slab_sums(const float* __restrict__ part, int slabs, int C, int c, double (&red)[2][8][32],
+                                          double& s, double& q) {
+    const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int sb = l; sb < slabs; sb += 8) { a += part[((size_t)sb * 2) * C + c]; b += part[((size_t)sb * 2 + 1) * C + c]; }
+    red[0][l][cl] = a;
+    red[1][l][cl] = b;
+    __syncthreads();
+    s = q = 0.0;
+    if (l == 0)
+        for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+}
+
 // forward finalize: mean, invstd, running statistics (nn.BatchNorm2d: momentum update with the UNBIASED variance)
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int slabs, long M, int C, float eps, float momentum,
-                                      float* __restrict__ mean, float* __restrict__ invstd,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < slabs; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part, int slabs, long M, int C, float eps,
+                                                             float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
+    __shared__ double red[2][8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double s, q;
+    slab_sums(part, slabs, C, c, red, s, q);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
     const double mu = s / (double)M;
     double var = q / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -137,12 +154,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int slabs, int C, float* __restrict__ sums,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < slabs; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int slabs, int C, float* __restrict__ sums,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2][8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double s, q;
+    slab_sums(part, slabs, C, c, red, s, q);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
     sums[c] = (float)s;
     sums[C + c] = (float)q;
     if (dbeta) dbeta[c] = (float)s;
@@ -305,7 +323,7 @@ extern "C" int i2l_bn_train_fwd_bf16(const void* z, const void* residual, const 
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(slabs), dim3(256), 0, s, static_cast<const bf16_t*>(z), nullptr, nullptr,
                        nullptr, nullptr, (long)M, C, part);
     I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(i2l_cdiv(C, 128)), dim3(128), 0, s, part, slabs, (long)M, C, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(i2l_cdiv(C, 32)), dim3(256), 0, s, part, slabs, (long)M, C, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var);
     I2L_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 0, s, static_cast<const bf16_t*>(z),
@@ -329,7 +347,7 @@ extern "C" int i2l_bn_train_bwd_bf16(const float* dy, const void* y_relu, const 
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(slabs), dim3(256), 0, s, static_cast<const bf16_t*>(z), dy,
                        static_cast<const bf16_t*>(y_relu), save_mean, save_invstd, (long)M, C, part);
     I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(i2l_cdiv(C, 128)), dim3(128), 0, s, part, slabs, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(i2l_cdiv(C, 32)), dim3(256), 0, s, part, slabs, C, sums, dgamma, dbeta);
     I2L_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 0, s, dy, static_cast<const bf16_t*>(y_relu),
                        static_cast<const bf16_t*>(z), gamma, save_mean, save_invstd, sums, (long)M, C, dz, dres,
