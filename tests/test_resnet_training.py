@@ -107,7 +107,9 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
         mag = yn.abs() + (u["residual"].float().abs() if u["residual"] is not None else 0.0)   # one bf16 ulp of either term
         yn = _bf(yn) + (u["residual"].float() if u["residual"] is not None else 0.0)
         yn = torch.relu(yn) if u["relu"] else yn
-        assert float(((yf - yn).abs() - 2.0 ** -7 * mag).max()) <= 1e-5 * max(1.0, float(yn.abs().max()))
+        # two bf16 roundings (the normalised value, then the sum), the first of which may fall on the neighbouring bf16
+        # when the fp32 expression is evaluated in another order: <= 1.5 ulp(norm) + 0.5 ulp(y), ulp(v) <= 2^-7 |v|
+        assert float(((yf - yn).abs() - 2.0 ** -6 * mag).max()) <= 1e-5 * max(1.0, float(yn.abs().max()))
         worst["y"] = max(worst["y"], _rel(yf, ref["y"]))
         key = next(n for n, mod in enc.named_modules() if mod is u["bn"])
         M = zf.numel() // zf.shape[-1]
