@@ -85,6 +85,13 @@ def test_cli_surface_matches_the_reference():
         assert opt in r.stdout, opt
     with pytest.raises(SystemExit):
         cli.predict(PT, PNG, device="cpu")
+    if not torch.cuda.is_available():                    # no GPU: a clear refusal, never a CPU computation
+        with pytest.raises(SystemExit) as e:
+            cli.main(["predict", PT, PNG])
+        assert "ROCm" in str(e.value)
+        with pytest.raises(SystemExit) as e:
+            cli._device(None)
+        assert "ROCm" in str(e.value)
 
 
 # ------------------------------------------------------------------------------------------------------------ GPU
