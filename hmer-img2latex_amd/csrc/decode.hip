@@ -56,7 +56,9 @@ Layout make_layout(int rows, int V, int E, int H, int L) {
     if (group_shape_ok(V, H, L)) {
         o.n_groups = i2l_cdiv(rows, 4);
         o.xchg = off;
-        o.xchg_bytes = GROUP_STATUS_BYTES + (size_t)i2l_cdiv(o.n_groups, 8) * 8 * GROUP_XCHG_PER_GROUP;
+        const size_t x4 = (size_t)i2l_cdiv(o.n_groups, 8) * 8 * GROUP_XCHG_PER_GROUP;
+        const size_t x8 = (size_t)i2l_cdiv(i2l_cdiv(rows, 8), 8) * 8 * (2 * GROUP_XCHG_PER_GROUP);   // 8 members x 8 rows (decode_group8)
+        o.xchg_bytes = GROUP_STATUS_BYTES + (x4 > x8 ? x4 : x8);
         off += i2l_align(o.xchg_bytes);
     }
     o.total = off;
@@ -395,6 +397,7 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned row
 }
 
 #include "decode_group.inc.h"
+#include "decode_group8.inc.h"
 #include "beam_group.inc.h"
 
 // KR / KL > 0 (fast path for R == 1, L == 1, H <= 256: thread j owns hidden unit j for the whole loop):
@@ -1049,6 +1052,27 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
     if (rows_per_wg == 0 && lo.xchg_bytes && (select == I2L_SELECT_LOGITS || select == I2L_SELECT_SOFTMAX) && !h0 &&
         !h_out && !c_out &&
         steps >= 8 && steps <= 65000) {   // the candidate granule carries step + 1 in 16 bits
+        if ((flags & I2L_FLAG_DECODE_GROUP8) && !logits_out && !forced && ids_out) {
+            // eight members x eight rows: one wave per SIMD and ~80 KB of LDS per CU, i.e. room for a conv workgroup beside it
+            static_assert(GROUP8_XCHG_PER_GROUP == 2 * GROUP_XCHG_PER_GROUP, "exchange region sizing");
+            GroupParams gp{};
+            gp.w = p.w; gp.B = rows; gp.T = steps; gp.n_groups = i2l_cdiv(rows, 8);
+            gp.tok0 = tok0; gp.forced = nullptr; gp.ids = ids_out; gp.logits = nullptr;
+            gp.temperature = temperature; gp.use_temp = p.use_temp; gp.stop = stop; gp.end_id = end_id;
+            char* xb = const_cast<char*>(base) + lo.xchg;
+            gp.status = reinterpret_cast<unsigned*>(xb);
+            gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
+            gp.opts = group_opts(steps, flags);
+            hipStream_t gs = i2l_s(stream);
+            static const hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group8_kernel),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP8_LDS);
+            if (attr8 == hipSuccess) {
+                if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
+                hipLaunchKernelGGL(decode_group8_kernel, dim3(i2l_cdiv(gp.n_groups, 8) * 64), dim3(G8NT), GRP8_LDS, gs, gp);
+                I2L_CHECK_LAUNCH();
+                return I2L_OK;
+            }
+        }
         GroupParams gp{};
         gp.w = p.w; gp.B = rows; gp.T = steps; gp.n_groups = lo.n_groups;
         gp.tok0 = tok0; gp.forced = forced; gp.ids = ids_out; gp.logits = logits_out;

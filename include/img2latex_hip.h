@@ -62,6 +62,10 @@ typedef void* i2l_stream_t;
                                           step) for a workgroup's first poll and 3 s for the later ones               */
 #define I2L_FLAG_TEST_DROP_MEMBER 0x80 /* grouped kernels, TEST hook: member 3 of every group exits at once, so its peers
                                           time out: exercises the failure path (ids -3 / len -3 / NaN, host fallback)  */
+#define I2L_FLAG_DECODE_GROUP8 0x1000  /* i2l_greedy_decode_ex (ids only: no logits_out, no forced tokens): the grouped kernel
+                                          with EIGHT members x EIGHT rows per group -- one wave per SIMD and ~80 KB of LDS
+                                          per CU instead of two waves and 140 KB, so that a conv workgroup of the NEXT
+                                          batch's encoder fits beside it; same ids                                   */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
 
 int i2l_version(void);

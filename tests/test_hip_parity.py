@@ -965,3 +965,44 @@ def test_encoder_reuses_packed_filters_until_a_weight_changes():
         fresh2 = fresh2.to(DEV).eval()
         assert torch.equal(m.encoder(xb), fresh2.encoder(xb))
         w.div_(1.25)
+
+
+@pytest.mark.parametrize("fname", ["primary_cfg2_clock", "primary_cfg2"])
+def test_group8_decode_ids_vs_reference(fname):
+    """decode_group8_kernel (8 members x 8 rows per group: one wave per SIMD, ~80 KB of LDS, the footprint that shares a
+    CU with a conv workgroup) on BASELINE configs[1] at full size: ids against the reference's fixture with the margin
+    guard, both stop rules, temperature, ragged batch sizes (last group partly empty), the forced time-out path."""
+    d, cfg, sd_kw = load(fname)
+    m, _ = model_for(fname, sd_kw, cfg)
+    ref_ids = d["ids"].astype(np.int64)
+    steps = ref_ids.shape[1] - 1
+    x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(DEV)
+    G8 = _lib.FLAG_DECODE_GROUP8
+    with torch.no_grad():
+        enc = m.encoder(x)
+        ids8, _ = m.greedy_ids(enc, START, END, 150, flags=G8)
+        st = m.decoder.group_status()
+        assert st["groups"] == 32 and not st["timed_out"]                   # 256 rows / 8: it WAS the 8-member kernel
+        record(f"{fname} group8 decode, 32 groups: groups whose 8 members share one XCD", st["groups_on_one_xcd"])
+        ids4, _ = m.greedy_ids(enc, START, END, 150)
+        got8 = _lib.check_ids(ids8.cpu()).numpy()[:, :steps]
+        assert _margin_guard(got8, ref_ids, d["margins"], tol=2e-4) <= 0.05 * 256
+        assert int((got8 != _lib.check_ids(ids4.cpu()).numpy()[:, :steps]).any(axis=1).sum()) <= 3   # near-ties only
+        # sticky stop + argmax of softmax, temperature
+        a, _ = m.greedy_ids(enc, START, END, 60, temperature=0.7, stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX, flags=G8)
+        b, _ = m.greedy_ids(enc, START, END, 60, temperature=0.7, stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX)
+        a, b = _lib.check_ids(a.cpu()), _lib.check_ids(b.cpu())
+        assert int((a != b).any(dim=1).sum()) <= 3
+        # ragged batches: 1 .. 19 rows, 77 rows (last group holds 5)
+        for B in (1, 7, 8, 9, 19, 77):
+            e = enc[:B].contiguous()
+            p8, _ = m.greedy_ids(e, START, END, 40, flags=G8)
+            p4, _ = m.greedy_ids(e, START, END, 40)
+            p8, p4 = _lib.check_ids(p8.cpu()).numpy(), _lib.check_ids(p4.cpu()).numpy()
+            assert _margin_guard(p8, ref_ids[:B], d["margins"][:B], tol=2e-4) <= 1, B
+            assert p8.shape == p4.shape
+        # forced time-out: returns in milliseconds with ids -3
+        tok0 = torch.full((64,), START, dtype=torch.int32, device=DEV)
+        bad, _, _ = m.decoder.run_steps(enc[:64].contiguous(), 40, tok0,
+                                        flags=G8 | _lib.FLAG_TEST_DROP_MEMBER | _lib.FLAG_TEST_SHORT_TIMEOUT)
+        assert bool((bad == -3).all())
