@@ -79,6 +79,9 @@ def main():
                     help="greedy = the headline (BASELINE configs[1]); beam = configs[2] (128 images x k=5, attention); "
                          "train = configs[3] (teacher-forced fwd+bwd+CE+clip+Adam, 64 samples/GPU, RCCL all-reduce); "
                          "resnet = configs[4] (ResNet50 encoder in bf16 + greedy decode, batch 256)")
+    ap.add_argument("--coresident", action="store_true",
+                    help="with --pipelined: the decode of batch i runs on the 8-member grouped kernel (one wave per SIMD, 80 KB "
+                         "of LDS per CU) so that the conv workgroups of batch i + 1's encoder share every CU with it")
     ap.add_argument("--serial", action="store_true", help="(default) time batches back to back on one stream")
     ap.add_argument("--pipelined", action="store_true",
                     help="time the two-stream batch pipeline (encoder of batch i+1 beside the decode of batch i, "
@@ -184,7 +187,8 @@ def main():
         serial_elapsed = elapsed
     else:
         pipe = GreedyPipeline(model, synth.START, synth.END, T, depth=args.pipe_depth,
-                              rows_per_workgroup=args.pipe_rows, decode_streams=args.pipe_decoders)
+                              rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
+                              decode_flags=_lib.FLAG_DECODE_GROUP8 if args.coresident else 0)
 
         def pipe_step():
             if pipe.pending() >= pipe.depth:

@@ -26,7 +26,8 @@ class GreedyPipeline:
     """submit(images) enqueues one batch; results come back in order from collect()."""
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
-                 temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1):
+                 temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
+                 decode_flags: int = 0):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -40,6 +41,10 @@ class GreedyPipeline:
         self._next_dec = 0
         self.depth = max(depth, len(self.dec_streams) + 1)
         self.rows_per_workgroup = rows_per_workgroup     # 2: decode occupies half of the CUs, the encoder the rest
+        # r03: decode_flags = _lib.FLAG_DECODE_GROUP8 (with rows_per_workgroup = 0) runs the 8-member grouped decode
+        # instead -- one wave per SIMD and 80 KB of LDS on EVERY CU, which leaves room for one conv workgroup of the next
+        # batch's encoder on the same CU: the two kernels share the chip by resource, not by CU count
+        self.decode_flags = int(decode_flags)
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor]] = deque()
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
         self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
@@ -62,7 +67,7 @@ class GreedyPipeline:
                 dec_stream.wait_event(enc_done)
                 enc.record_stream(dec_stream)
                 ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
-                                               rows_per_workgroup=self.rows_per_workgroup)
+                                               rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags)
                 host = self._host_buffer(ids.shape)
                 host.copy_(ids, non_blocking=True)
                 done = torch.cuda.Event()
