@@ -27,7 +27,7 @@ class GreedyPipeline:
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
-                 decode_flags: int = 0):
+                 decode_flags: int = 0, encoder_flags: int = 0):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -45,6 +45,7 @@ class GreedyPipeline:
         # instead -- one wave per SIMD and 80 KB of LDS on EVERY CU, which leaves room for one conv workgroup of the next
         # batch's encoder on the same CU: the two kernels share the chip by resource, not by CU count
         self.decode_flags = int(decode_flags)
+        self.encoder_flags = int(encoder_flags)          # e.g. _lib.FLAG_CONV_ONE_PER_CU while the pipeline runs
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor]] = deque()
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
         self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
@@ -57,7 +58,12 @@ class GreedyPipeline:
         self.enc_stream.wait_stream(cur)                      # images were produced on the caller's stream
         with torch.no_grad():
             with torch.cuda.stream(self.enc_stream):
-                enc = self.model.encoder(images)
+                saved = self.model.encoder.kernel_flags
+                self.model.encoder.kernel_flags = saved | self.encoder_flags
+                try:
+                    enc = self.model.encoder(images)
+                finally:
+                    self.model.encoder.kernel_flags = saved
                 enc_done = torch.cuda.Event()
                 enc_done.record(self.enc_stream)
             images.record_stream(self.enc_stream)
