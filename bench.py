@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--coresident", action="store_true",
                     help="with --pipelined: the decode of batch i runs on the 8-member grouped kernel (one wave per SIMD, 80 KB "
                          "of LDS per CU) so that the conv workgroups of batch i + 1's encoder share every CU with it")
-    ap.add_argument("--conv-two-per-cu", action="store_true", help="with --coresident: keep the conv blocks at two workgroups per CU")
+    ap.add_argument("--decode-priority", type=int, default=0, help="with --pipelined: HIP stream priority of the decode stream (-1 = high)")
     ap.add_argument("--serial", action="store_true", help="(default) time batches back to back on one stream")
     ap.add_argument("--pipelined", action="store_true",
                     help="time the two-stream batch pipeline (encoder of batch i+1 beside the decode of batch i, "
@@ -190,7 +190,7 @@ def main():
         pipe = GreedyPipeline(model, synth.START, synth.END, T, depth=args.pipe_depth,
                               rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
                               decode_flags=_lib.FLAG_DECODE_GROUP8 if args.coresident else 0,
-                              encoder_flags=_lib.FLAG_CONV_ONE_PER_CU if (args.coresident and not args.conv_two_per_cu) else 0)
+                              decode_priority=args.decode_priority)
 
         def pipe_step():
             if pipe.pending() >= pipe.depth:

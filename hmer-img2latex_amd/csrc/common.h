@@ -55,7 +55,7 @@ bool i2l_conv_bf16x3_full_applicable(int Cin, int Cout);   // the full-resolutio
 size_t i2l_conv_bf16x3_workspace_bytes(int Cin, int Cout);
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
                         int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, int full = 0,
-                        int weights_packed = 0, int one_per_cu = 0);
+                        int weights_packed = 0);
 // (full != 0: plain full-resolution conv with the flipped / transposed filter = a block's data gradient; H, W even)
 // first conv block (Cin <= 3): whole K in one or two bf16 k-steps, filters in registers, im2col image in LDS
 bool i2l_conv_smallk_applicable(int Cin, int Cout);

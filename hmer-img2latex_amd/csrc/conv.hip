@@ -477,7 +477,7 @@ extern "C" int i2l_conv3x3_relu_pool2_fwd(const float* x, const float* w, const 
         return i2l_conv_smallk_run(x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream));
     if (split && i2l_conv_bf16x3_applicable(Cin, Cout))
         return i2l_conv_bf16x3_run(x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream), 0,
-                                   (flags & I2L_FLAG_WEIGHTS_PACKED) ? 1 : 0, (flags & I2L_FLAG_CONV_ONE_PER_CU) ? 1 : 0);
+                                   (flags & I2L_FLAG_WEIGHTS_PACKED) ? 1 : 0);
     return run_conv(true, x, w, bias, y, argmax_out, B, Cin, H, W, Cout, workspace, workspace_bytes, i2l_s(stream), exact);
 }
 

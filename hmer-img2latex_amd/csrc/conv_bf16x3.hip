@@ -635,7 +635,7 @@ int launch_fixup(const float* x, const float* w, const float* bias, float* y, un
 
 int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float* y, unsigned char* amax, int B, int Cin,
                         int H, int W, int Cout, void* workspace, size_t workspace_bytes, hipStream_t s, int full,
-                        int weights_packed, int one_per_cu) {
+                        int weights_packed) {
     if (full && ((H | W) & 1)) return I2L_ERR_UNSUPPORTED;       // full resolution is written quad by quad
     const size_t pack_bytes = i2l_conv_bf16x3_workspace_bytes(Cin, Cout);
     if (workspace_bytes < pack_bytes + (amax ? i2l_conv_fixlist_bytes() : 0) || !workspace) return I2L_ERR_WORKSPACE;
@@ -669,9 +669,7 @@ int i2l_conv_bf16x3_run(const float* x, const float* w, const float* bias, float
     const long long n_items_ll = (long long)tiles_per_img * B;
     if (n_items_ll > 0x7fffffffll) return I2L_ERR_UNSUPPORTED;
     const int n_items = (int)n_items_ll;
-    // one_per_cu (I2L_FLAG_CONV_ONE_PER_CU): 256 walks instead of 512, i.e. one workgroup per CU, so that a co-resident
-    // decode workgroup (decode_group8_kernel: 80 KB of LDS, one wave per SIMD) always finds room beside it
-    int items_per_wg = (int)((n_items_ll * co_blocks + (one_per_cu ? 255 : 511)) / (one_per_cu ? 256 : 512));
+    int items_per_wg = (int)((n_items_ll * co_blocks + 511) / 512);
     // a launch with little more than one resident round of single tiles (block 3 of a 64-image training batch: 640):
     // one tile per workgroup fills the CUs more evenly than 320 walks of two (86 -> 73 us); measured worse above that
     if (n_items_ll * co_blocks <= 768) items_per_wg = 1;

@@ -24,7 +24,6 @@ MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
 FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0x1, 0x2, 0x4, 0x8
 FLAG_WEIGHTS_PACKED = 0x10          # conv forward: the workspace still holds the packed filters of these weights
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
-FLAG_CONV_ONE_PER_CU = 0x2000        # conv blocks 2 / 3: one workgroup per CU (beside a co-resident decode workgroup)
 FLAG_DECODE_GROUP8 = 0x1000          # greedy decode: 8 members x 8 rows per group (co-resident with a conv workgroup)
 FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks of the grouped kernels
 

@@ -27,7 +27,7 @@ class GreedyPipeline:
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
-                 decode_flags: int = 0, encoder_flags: int = 0):
+                 decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -37,7 +37,7 @@ class GreedyPipeline:
         self.enc_stream = torch.cuda.Stream(device=dev)
         # several decode streams (round robin) let decodes of consecutive batches run side by side, each on
         # few CUs (more rows per workgroup = less weight traffic per row); depth must cover them
-        self.dec_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, decode_streams))]
+        self.dec_streams = [torch.cuda.Stream(device=dev, priority=int(decode_priority)) for _ in range(max(1, decode_streams))]
         self._next_dec = 0
         self.depth = max(depth, len(self.dec_streams) + 1)
         self.rows_per_workgroup = rows_per_workgroup     # 2: decode occupies half of the CUs, the encoder the rest

@@ -66,8 +66,6 @@ typedef void* i2l_stream_t;
                                           with EIGHT members x EIGHT rows per group -- one wave per SIMD and ~80 KB of LDS
                                           per CU instead of two waves and 140 KB, so that a conv workgroup of the NEXT
                                           batch's encoder fits beside it; same ids                                   */
-#define I2L_FLAG_CONV_ONE_PER_CU 0x2000 /* i2l_conv3x3_relu_pool2_fwd (split-bf16 blocks): 256 resident workgroups instead of 512,
-                                          one per CU, leaving room for a co-resident decode workgroup (GreedyPipeline)    */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
 
 int i2l_version(void);
