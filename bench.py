@@ -210,7 +210,10 @@ def main():
         ids_pipe = last[0].clone()
         serial_elapsed = timed(serial_step, lambda: None, hooked=True)  # per-kernel times, undisturbed
         last[0] = ids_host
-        assert torch.equal(ids_pipe, ids_host), "pipeline and serial search disagree"
+        # the two regions run different decode kernels (8-member / 4-member groups: fp32 sums in another order), so a row may
+        # leave the other region's ids at an fp32 near-tie; BOTH are held against the reference's ids below (margin guard)
+        differing = int((ids_pipe != ids_host).any(dim=1).sum())
+        assert differing <= 0.02 * B, f"pipelined and serial search disagree on {differing} rows"
         pipelined_elapsed = elapsed
         if serial_elapsed < elapsed:       # stream overlap is up to the hardware queues: never report worse than serial
             elapsed = serial_elapsed
@@ -337,6 +340,9 @@ def main():
     # ---- outside the timed region: the decode must not have timed out, and the ids must be the reference's
     _lib.check_ids(ids_host)
     result["ids_check"] = golden_ids_check(ids_host, B, T, rank)
+    if not args.serial:
+        _lib.check_ids(ids_pipe)
+        result["ids_check_pipelined"] = golden_ids_check(ids_pipe, B, T, rank)
     # ---- beside the kernel-only headline (NOT `value`): the same batch through the reference-shaped entry points
     if rank == 0 and world == 1:
         result["beside"] = beside_paths(model, cfg, images, B, T, max(3, min(10, args.steps)))

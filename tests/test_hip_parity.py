@@ -1006,3 +1006,33 @@ def test_group8_decode_ids_vs_reference(fname):
         bad, _, _ = m.decoder.run_steps(enc[:64].contiguous(), 40, tok0,
                                         flags=G8 | _lib.FLAG_TEST_DROP_MEMBER | _lib.FLAG_TEST_SHORT_TIMEOUT)
         assert bool((bad == -3).all())
+
+
+def test_coresident_pipeline_ids_vs_reference():
+    """GreedyPipeline with the 8-member grouped decode (FLAG_DECODE_GROUP8) sharing every CU with the next batch's conv
+    workgroups: six batches of BASELINE configs[1] (three distinct image sets, so that consecutive batches differ) through
+    the two-stream pipeline -- every batch's ids against the reference's fixture (margin guard) for the fixture's images
+    and equal to the one-batch-at-a-time search for the others up to near-ties; nothing times out."""
+    from img2latex_amd.pipeline import GreedyPipeline
+    d, cfg, sd_kw = load("primary_cfg2")
+    m, _ = model_for("primary_cfg2", sd_kw, cfg)
+    ref_ids = d["ids"].astype(np.int64)
+    steps = ref_ids.shape[1] - 1
+    sets = [torch.from_numpy(synth.make_images(256, cfg, seed=s)).to(DEV) for s in (1234, 77, 78)]
+    with torch.no_grad():
+        want = [_lib.check_ids(m.greedy_ids(m.encoder(x), START, END, 150)[0].cpu()).numpy() for x in sets]
+    pipe = GreedyPipeline(m, START, END, 150, depth=2, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8,
+                          decode_priority=-1)
+    order = [0, 1, 2, 0, 2, 1]
+    got = []
+    for i in order:
+        if pipe.pending() >= 2:
+            got.append(pipe.collect().numpy().copy())
+        pipe.submit(sets[i])
+    while pipe.pending():
+        got.append(pipe.collect().numpy().copy())
+    assert len(got) == 6
+    for i, g in zip(order, got):
+        assert int((g != want[i]).any(axis=1).sum()) <= 3, i               # the other kernel's sums: near-ties only
+        if i == 0:
+            assert _margin_guard(g[:, :steps], ref_ids, d["margins"], tol=2e-4) <= 0.05 * 256
