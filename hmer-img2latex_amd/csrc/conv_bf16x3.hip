@@ -133,9 +133,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
     int tiles_x, int n_chunks, int tiles_per_img, int n_items, int items_per_wg, unsigned* __restrict__ fix) {
     typedef Tile3<WX> TL;
     constexpr int PR = TL::TR / 2, PC = TL::TC / 2;
-    // issue priority over co-resident waves of OTHER kernels (GreedyPipeline runs the 8-member grouped decode of the previous
-    // batch on the same SIMDs: its vector-FMA bursts must not hold back this wave's MFMA issue); no effect when alone
-    __builtin_amdgcn_s_setprio(2);
     __shared__ __attribute__((aligned(16))) uint4 in_s[TL::IN_U4];
     __shared__ __attribute__((aligned(16))) uint4 w_s[W_PHASE_U4];             // the 3 taps of one filter row
     __shared__ float out_s[CO_BLK * 65];                                       // fp32 staging of the pooled tile
