@@ -303,6 +303,22 @@ def main():
                                    frac_bf16_executed_of_sustained=round(6.0 * e_flops / e_ms / 1e9 / SUSTAINED_BF16_TFLOPS, 4),
                                    note="algorithmic bytes / flops (SURVEY 8d); executed = 6 bf16 partial products per fp32 product; sustained = "
                                         "what bare MFMA loops reach on random operands (1.82 of the nominal 2.5 PFLOP/s)")
+    if not args.serial and args.coresident:
+        # the timed region's decode kernel, alone on the chip (in the pipelined region it shares every CU with conv workgroups)
+        with torch.no_grad():
+            enc_ = model.encoder(images)
+            for _ in range(3):
+                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8)
+            ev8 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev8[0].record()
+            for _ in range(10):
+                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8)
+            ev8[1].record()
+            torch.cuda.synchronize()
+        roofline["timed_region_decode"] = dict(
+            kernel="decode_group8_kernel", prepare_plus_decode_alone_ms=round(ev8[0].elapsed_time(ev8[1]) / 10, 4),
+            note="8 members x 8 rows per group, one wave per SIMD and 80 KB of LDS per CU: in the timed region it shares every CU "
+                 "with the conv workgroups of the next batch; the stage times above are the SERIAL pass's (4-member kernel)")
     roofline["stages"] = stages
     roofline["measured_in"] = ("the timed region" if args.serial else
                                f"a serial pass of {args.steps} steps right after the timed region (one stream, whole chip per "

@@ -8,8 +8,8 @@ ROUND=${1:-r01}; TAG=${2:-v3}
 OUT=gpurun_out/prof_${ROUND}_${TAG}
 export TMPDIR=/tmp
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python bench.py --steps 20 --warmup 3 > $OUT/stats.log 2>&1
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python bench.py --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- python bench.py --steps 3 --warmup 1 > $OUT/write.log 2>&1
 # matrix-pipe busy cycles (summed over all SIMDs) and the GPU-active clock count (summed over the 8 XCDs)
