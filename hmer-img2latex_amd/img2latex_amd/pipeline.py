@@ -46,7 +46,7 @@ class GreedyPipeline:
         # batch's encoder on the same CU: the two kernels share the chip by resource, not by CU count
         self.decode_flags = int(decode_flags)
         self.encoder_flags = int(encoder_flags)          # e.g. _lib.FLAG_CONV_ONE_PER_CU while the pipeline runs
-        self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor]] = deque()
+        self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor, torch.Tensor]] = deque()
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
         self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
 
@@ -78,7 +78,7 @@ class GreedyPipeline:
                 host.copy_(ids, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(dec_stream)
-        self._inflight.append((done, host))
+        self._inflight.append((done, host, enc))
 
     def _host_buffer(self, shape) -> torch.Tensor:
         for i, t in enumerate(self._free):
@@ -94,8 +94,18 @@ class GreedyPipeline:
         collect(); ``to_sequences`` applies the reference's stop rule and list conversion."""
         if not self._inflight:
             return None
-        done, host = self._inflight.popleft()
+        done, host, enc = self._inflight.popleft()
         done.synchronize()
+        if _lib.ids_timed_out(host):
+            # a grouped decode needs its members resident together; on a GPU shared with other work a bounded wait can
+            # expire (ids -3): this batch is decoded again on the row-per-workgroup kernel, which needs no partner
+            import warnings
+            warnings.warn("img2latex_amd: grouped decode timed out inside the pipeline; re-running the batch on the "
+                          "row-per-workgroup kernel", RuntimeWarning)
+            with torch.no_grad():
+                ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
+                                               rows_per_workgroup=1)
+            host.copy_(ids)
         if self._lent is not None:
             self._free.append(self._lent)
         self._lent = host

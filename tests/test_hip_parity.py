@@ -1036,3 +1036,25 @@ def test_coresident_pipeline_ids_vs_reference():
         assert int((g != want[i]).any(axis=1).sum()) <= 3, i               # the other kernel's sums: near-ties only
         if i == 0:
             assert _margin_guard(g[:, :steps], ref_ids, d["margins"], tol=2e-4) <= 0.05 * 256
+
+
+def test_pipeline_falls_back_when_the_grouped_decode_times_out():
+    """A batch whose grouped decode timed out (forced: silent member + 2 ms limits) is decoded again on the
+    row-per-workgroup kernel inside GreedyPipeline.collect(): same ids as the healthy pipeline, one warning per batch."""
+    from img2latex_amd.pipeline import GreedyPipeline
+    d, cfg, sd_kw = load("primary_cfg2_clock")
+    m, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    x = torch.from_numpy(synth.make_images(64, cfg, seed=1234)).to(DEV)
+    good = GreedyPipeline(m, START, END, 60, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8)
+    good.submit(x)
+    want = good.collect().clone()
+    bad = GreedyPipeline(m, START, END, 60, rows_per_workgroup=0,
+                         decode_flags=_lib.FLAG_DECODE_GROUP8 | _lib.FLAG_TEST_DROP_MEMBER | _lib.FLAG_TEST_SHORT_TIMEOUT)
+    bad.submit(x)
+    bad.submit(x)
+    with pytest.warns(RuntimeWarning):
+        a = bad.collect().clone()
+    with pytest.warns(RuntimeWarning):
+        b = bad.collect().clone()
+    assert torch.equal(a, b)
+    assert int((a != want).any(dim=1).sum()) <= 2                      # the fallback kernel's sums: near-ties only
