@@ -1,0 +1,45 @@
+"""ResNet-50 encoder + greedy decode (BASELINE configs[4]): serial against the co-resident two-stream pipeline."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "hmer-img2latex_amd"))
+from img2latex_amd import _lib, synth
+from img2latex_amd.model import Seq2SeqModel
+from img2latex_amd.pipeline import GreedyPipeline
+dev = torch.device("cuda:0")
+cfg = synth.model_config()
+enc_p = dict(img_height=64, img_width=320, channels=3, model_name="resnet50", embedding_dim=256, freeze_backbone=True)
+model = Seq2SeqModel("resnet_lstm", cfg["vocab_size"], enc_p, synth.decoder_params(cfg))
+shapes = [(k, tuple(v.shape)) for k, v in model.encoder.state_dict().items()]
+full = {"encoder." + k: torch.from_numpy(v) for k, v in synth.make_resnet_state_dict(shapes, seed=5).items()}
+full.update({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=42, out_scale=8.0).items() if k.startswith("decoder.")})
+model.load_state_dict(full)
+model = model.to(dev).eval()
+x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(dev)
+N = 60
+with torch.no_grad():
+    for _ in range(10):
+        ids, _ = model.greedy_ids(model.encoder(x), synth.START, synth.END, 150)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(N):
+        ids, _ = model.greedy_ids(model.encoder(x), synth.START, synth.END, 150)
+        h = ids.cpu()
+    torch.cuda.synchronize(); serial = (time.perf_counter() - t0) / N
+want = h.clone()
+for flags, name in ((_lib.FLAG_DECODE_GROUP8, "co-resident (8-member decode)"),):
+    pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=flags, decode_priority=-1)
+    last = None
+    def run(n):
+        global last
+        for _ in range(n):
+            if pipe.pending() >= pipe.depth:
+                last = pipe.collect()
+            pipe.submit(x)
+        while pipe.pending():
+            last = pipe.collect()
+    run(10)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run(N)
+    torch.cuda.synchronize(); piped = (time.perf_counter() - t0) / N
+    diff = int((last != want).any(dim=1).sum())
+    print(f"resnet50 + greedy decode, B=256: serial {serial * 1e3:.3f} ms per batch ({256 * 150 / serial / 1e6:.2f} M tokens/s), "
+          f"{name} {piped * 1e3:.3f} ms ({256 * 150 / piped / 1e6:.2f} M tokens/s), rows differing from serial {diff}")
