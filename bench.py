@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--pipe-rows", type=int, default=2, help="decode rows per workgroup in the pipelined region")
     ap.add_argument("--pipe-decoders", type=int, default=1, help="decode streams in the pipelined region")
     ap.add_argument("--pipe-depth", type=int, default=2, help="batches in flight in the pipelined region")
+    ap.add_argument("--pipe-encoders", type=int, default=None,
+                    help="encoder streams in the pipelined region (default 1; 2 for --mode resnet: two trunks side by side "
+                         "fill each other's launch gaps and tile tails)")
     ap.add_argument("--mode", choices=["greedy", "beam", "train", "resnet", "preprocess", "metrics"], default="greedy",
                     help="greedy = the headline (BASELINE configs[1]); beam = configs[2] (128 images x k=5, attention); "
                          "train = configs[3] (teacher-forced fwd+bwd+CE+clip+Adam, 64 samples/GPU, RCCL all-reduce); "
@@ -195,7 +198,7 @@ def main():
         pipe = GreedyPipeline(model, synth.START, synth.END, T, depth=args.pipe_depth,
                               rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
                               decode_flags=_lib.FLAG_DECODE_GROUP8 if args.coresident else 0,
-                              decode_priority=args.decode_priority)
+                              decode_priority=args.decode_priority, encoder_streams=args.pipe_encoders or 1)
 
         def pipe_step():
             if pipe.pending() >= pipe.depth:
@@ -610,6 +613,7 @@ def extra_modes(args, world, rank, dev, dist):
         images = torch.from_numpy(synth.make_images(Bn, cfg, seed=1234 + rank)).to(dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         enc_ms = []
+        serial_ids = [None]
 
         def one_step():
             with torch.no_grad():
@@ -617,7 +621,7 @@ def extra_modes(args, world, rank, dev, dist):
                 enc = model.encoder(images)
                 ev[1].record()
                 ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
-                ids.cpu()
+                serial_ids[0] = ids.cpu()
                 enc_ms.append(ev[0].elapsed_time(ev[1]))
         unit = lambda: float(Bn * T)
         # ResNet-50 trunk at 64x320: 4.09 GMAC x (64*320)/(224*224)
@@ -770,16 +774,19 @@ def extra_modes(args, world, rank, dev, dist):
         # the same co-resident two-stream schedule as the headline: decode(i) on decode_group8_kernel beside the trunk of
         # batch i + 1 (the ring GEMMs with a 2-stage ring fit beside it, the 4-stage ones wait); the serial pass above keeps
         # providing the encoder's time for the roofline and is a floor for `value`
+        n_enc = args.pipe_encoders or 2
         pipe = GreedyPipeline(model, synth.START, synth.END, T, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8,
-                              decode_priority=args.decode_priority)
+                              decode_priority=args.decode_priority, encoder_streams=n_enc)
+
+        piped_ids = [None]
 
         def run_pipe(n):
             for _ in range(n):
                 if pipe.pending() >= pipe.depth:
-                    pipe.collect()
+                    piped_ids[0] = pipe.collect()
                 pipe.submit(images)
             while pipe.pending():
-                pipe.collect()
+                piped_ids[0] = pipe.collect()
         run_pipe(args.warmup)
         fence()
         t0 = time.perf_counter()
@@ -789,9 +796,16 @@ def extra_modes(args, world, rank, dev, dist):
         serial_value_note = round(units * args.steps / elapsed, 1)
         conf["value_serial"] = serial_value_note
         conf["value_pipelined"] = round(units * args.steps / piped, 1)
-        conf["batch_pipeline"] = ("2 streams, co-resident: decode(i) on decode_group8_kernel beside the ResNet trunk of batch i + 1"
+        conf["batch_pipeline"] = (f"{n_enc + 1} streams, co-resident: decode(i) on decode_group8_kernel beside the ResNet trunk(s) of the "
+                                  f"next {n_enc} batch(es)"
                                   if piped < elapsed else "serial")
         elapsed = min(elapsed, piped)
+        # outside the timed region: the pipelined batches decode to the ids of the serial pass (same images, same kernels
+        # for the trunk; the 8-member decode against the 4-member one -- rows may differ only at fp32 near-ties)
+        differ = int((piped_ids[0] != serial_ids[0]).any(dim=1).sum())
+        conf["ids_check_pipelined"] = f"{Bn - differ} of {Bn} rows equal the serial pass"
+        if differ > Bn // 50:
+            raise SystemExit(f"bench: pipelined resnet pass disagrees with the serial pass on {differ} rows")
     if dist is not None:
         tmax = torch.tensor([elapsed, 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -105,7 +105,7 @@ class ResNetEncoder(nn.Module):
         self.embedding_layer = nn.Linear(512 if kind == "basic" else 2048, embedding_dim)
         self.activation = nn.ReLU()
         self.model_name = model_name
-        self._ws: Optional[torch.Tensor] = None
+        self._ws = None            # {(device, stream): workspace bytes}
         self._packed = {}          # id(conv) -> (version key, packed bf16 filter + folded BatchNorm)
         self.cache_packed_weights = True
         self.kernel_flags = 0      # _lib.FLAG_RESNET_NO_RING / FLAG_RESNET_IM2COL_STEM / flag_resnet_ring_depth(n)
@@ -114,9 +114,13 @@ class ResNetEncoder(nn.Module):
 
     # ------------------------------------------------------------------
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-        return self._ws
+        key = (str(device), _lib.stream_ptr())              # one workspace per stream: pipelines run encoders side by side
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+        return ws
 
     def _conv_bn(self, x, shape, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, residual=None, nchw_f32=False):
         """One fused conv+BN(+residual)(+ReLU) launch; x is NHWC bf16 (or the NCHW fp32 images)."""

@@ -27,19 +27,22 @@ class GreedyPipeline:
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
-                 decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0):
+                 decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("img2latex_amd: GreedyPipeline needs the model on a ROCm device (no CPU fallback)")
         self.device = dev
-        self.enc_stream = torch.cuda.Stream(device=dev)
+        # several encoder streams (round robin): the encoders of consecutive batches run side by side, each one's launch
+        # gaps and tile tails filled by the other's workgroups (pays for the 53-launch ResNet trunk)
+        self.enc_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, encoder_streams))]
+        self._next_enc = 0
         # several decode streams (round robin) let decodes of consecutive batches run side by side, each on
         # few CUs (more rows per workgroup = less weight traffic per row); depth must cover them
         self.dec_streams = [torch.cuda.Stream(device=dev, priority=int(decode_priority)) for _ in range(max(1, decode_streams))]
         self._next_dec = 0
-        self.depth = max(depth, len(self.dec_streams) + 1)
+        self.depth = max(depth, len(self.dec_streams) + len(self.enc_streams))
         self.rows_per_workgroup = rows_per_workgroup     # 2: decode occupies half of the CUs, the encoder the rest
         # r03: decode_flags = _lib.FLAG_DECODE_GROUP8 (with rows_per_workgroup = 0) runs the 8-member grouped decode
         # instead -- one wave per SIMD and 80 KB of LDS on EVERY CU, which leaves room for one conv workgroup of the next
@@ -55,9 +58,11 @@ class GreedyPipeline:
         if len(self._inflight) >= self.depth:
             raise RuntimeError(f"GreedyPipeline: {self.depth} batches already in flight; collect() first")
         cur = torch.cuda.current_stream(self.device)
-        self.enc_stream.wait_stream(cur)                      # images were produced on the caller's stream
+        enc_stream = self.enc_streams[self._next_enc]
+        self._next_enc = (self._next_enc + 1) % len(self.enc_streams)
+        enc_stream.wait_stream(cur)                           # images were produced on the caller's stream
         with torch.no_grad():
-            with torch.cuda.stream(self.enc_stream):
+            with torch.cuda.stream(enc_stream):
                 saved = self.model.encoder.kernel_flags
                 self.model.encoder.kernel_flags = saved | self.encoder_flags
                 try:
@@ -65,8 +70,8 @@ class GreedyPipeline:
                 finally:
                     self.model.encoder.kernel_flags = saved
                 enc_done = torch.cuda.Event()
-                enc_done.record(self.enc_stream)
-            images.record_stream(self.enc_stream)
+                enc_done.record(enc_stream)
+            images.record_stream(enc_stream)
             dec_stream = self.dec_streams[self._next_dec]
             self._next_dec = (self._next_dec + 1) % len(self.dec_streams)
             with torch.cuda.stream(dec_stream):

@@ -25,8 +25,9 @@ with torch.no_grad():
         h = ids.cpu()
     torch.cuda.synchronize(); serial = (time.perf_counter() - t0) / N
 want = h.clone()
-for flags, name in ((_lib.FLAG_DECODE_GROUP8, "co-resident (8-member decode)"),):
-    pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=flags, decode_priority=-1)
+for flags, nenc, name in ((_lib.FLAG_DECODE_GROUP8, 1, "co-resident (8-member decode)"), (_lib.FLAG_DECODE_GROUP8, 2, "co-resident, 2 encoder streams"),
+                          (_lib.FLAG_DECODE_GROUP8, 3, "co-resident, 3 encoder streams")):
+    pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=flags, decode_priority=-1, encoder_streams=nenc)
     last = None
     def run(n):
         global last
