@@ -627,12 +627,39 @@ def extra_modes(args, world, rank, dev, dist):
         # ResNet-50 trunk at 64x320: 4.09 GMAC x (64*320)/(224*224)
         gflop = 2 * 4.09 * (64 * 320) / (224 * 224) * Bn
 
+        def layer_bytes():
+            """Algorithmic HBM bytes of the trunk AS A CHAIN OF LAYER KERNELS (every activation written once by its producer
+            and read once by each consumer, bf16; filters once): what bounds it at this batch and image size."""
+            model.encoder.trace = []
+            with torch.no_grad():
+                model.encoder(images)
+            torch.cuda.synchronize()
+            tot = 0.0
+            for conv, bn, x_, res_, y_, relu_, nchw in model.encoder.trace:
+                need = x_.numel() / (4 if (conv.kernel_size[0] == 1 and conv.stride[0] == 2) else 1)   # a strided 1x1 reads a quarter
+                tot += need * (4 if nchw else 2) + y_.numel() * 2 + conv.weight.numel() * 2
+                tot += res_.numel() * 2 if res_ is not None else 0
+            stem_out = model.encoder.trace[0][4].numel() * 2
+            tot += stem_out + stem_out / 4                       # 3x3 / 2 max-pool: reads the stem's output, writes a quarter
+            tot += model.encoder.trace[-1][4].numel() * 2        # global average pool
+            model.encoder.trace = None
+            return tot
+
         def roof(ms):
             e_ms = float(np.median(enc_ms[-args.steps:]))
+            byts = layer_bytes()
             return dict(bound="mfma", kernel="gemm_bf16_ring_kernel chain (53 conv launches of the trunk)",
                         achieved=round(gflop / e_ms, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                         frac=round(gflop / e_ms / PEAK_BF16_TFLOPS, 4), traffic=None, launch_ms=round(e_ms, 4),
-                        note="whole encoder (stem, max-pool, 52 GEMM-shaped convs, average pool, FC) against the dense bf16 peak")
+                        note="whole encoder (stem, max-pool, 52 GEMM-shaped convs, average pool, FC) against the dense bf16 peak "
+                             "(SURVEY 8d cfg5); see hbm_view: layer by layer the trunk at this size is nearer the HBM roofline",
+                        hbm_view=dict(algorithmic_bytes=round(byts), flop_per_byte=round(gflop * 1e9 / byts, 1),
+                                      ridge_flop_per_byte=round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
+                                      achieved_gbs=round(byts / e_ms / 1e6, 1), peak_gbs=PEAK_HBM_GBS,
+                                      frac=round(byts / e_ms / 1e6 / PEAK_HBM_GBS, 4),
+                                      note="every activation written once and read once per consumer (bf16), filters once: "
+                                           "below the ridge, i.e. as a chain of layer kernels the trunk is HBM-bound at "
+                                           "B=256 x 64x320; only cross-layer fusion moves this bound"))
 
         def cpu_base():
             import img2latex_oracle as O
