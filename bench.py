@@ -325,7 +325,9 @@ def main():
     roofline["stages"] = stages
     roofline["measured_in"] = ("the timed region" if args.serial else
                                f"a serial pass of {args.steps} steps right after the timed region (one stream, whole chip per "
-                               "kernel): in the pipelined region the decode runs on 128 CUs beside the encoder")
+                               "kernel): in the pipelined region " + ("decode_group8_kernel shares every CU with the next batch's conv "
+                               "workgroups (timed_region_decode has its time alone)" if args.coresident else
+                               "the decode runs on 128 CUs beside the encoder"))
 
     result = {
         "metric": "decoded LaTeX tokens/sec at batch 256, 320x64 imgs, seq 150",
@@ -797,6 +799,42 @@ def extra_modes(args, world, rank, dev, dist):
     elapsed = time.perf_counter() - t0
     units = unit()
     serial_value_note = None
+    if args.mode == "beam" and not args.serial:
+        # batches are independent: the encoder of batch i + 1 runs on a second stream beside the beam search of batch i
+        # (every batch still runs its own encoder and its own search; results checked below against the reference fixture)
+        enc_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+
+        def enqueue_encoder():
+            enc_stream.wait_stream(main)
+            with torch.no_grad(), torch.cuda.stream(enc_stream):
+                e = model.encoder(images)
+                ev = torch.cuda.Event()
+                ev.record(enc_stream)
+            return e, ev
+
+        def run_pipe(n_):
+            nxt = enqueue_encoder()
+            for _ in range(n_):
+                e, ev = nxt
+                main.wait_event(ev)
+                e.record_stream(main)
+                nxt = enqueue_encoder()
+                with torch.no_grad():
+                    out[0] = model.beam_search_batch(e, synth.START, synth.END, T, k)
+            main.wait_event(nxt[1])                  # the look-ahead encoder of the batch after the last one
+        run_pipe(args.warmup)
+        fence()
+        t0 = time.perf_counter()
+        run_pipe(args.steps)
+        fence()
+        piped = time.perf_counter() - t0
+        units = unit()
+        conf["value_serial"] = round(units * args.steps / elapsed, 1)
+        conf["value_pipelined"] = round(units * args.steps / piped, 1)
+        conf["batch_pipeline"] = ("2 streams: encoder(i+1) beside the beam search of batch i (one extra look-ahead encoder per "
+                                  "timed region is inside the time)" if piped < elapsed else "serial")
+        elapsed = min(elapsed, piped)
     if args.mode == "resnet" and not args.serial:
         # the same co-resident two-stream schedule as the headline: decode(i) on decode_group8_kernel beside the trunk of
         # batch i + 1 (the ring GEMMs with a 2-stage ring fit beside it, the 4-stage ones wait); the serial pass above keeps
