@@ -90,6 +90,7 @@ def main():
                          "co-resident one: decode of batch i on the 8-member grouped kernel (one wave per SIMD, 80 KB of LDS per "
                          "CU), the conv workgroups of batch i + 1's encoder on the same CUs")
     ap.add_argument("--decode-priority", type=int, default=-1, help="pipelined region: HIP stream priority of the decode stream (-1 = high)")
+    ap.add_argument("--encoder-priority", type=int, default=0, help="pipelined region: HIP stream priority of the encoder stream(s)")
     ap.add_argument("--serial", action="store_true", help="time only batches back to back on one stream (the r02 default)")
     ap.add_argument("--pipelined", action="store_true",
                     help="(default since r03) time the two-stream batch pipeline (GreedyPipeline: encoder of batch i+1 beside the "
@@ -198,7 +199,8 @@ def main():
         pipe = GreedyPipeline(model, synth.START, synth.END, T, depth=args.pipe_depth,
                               rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
                               decode_flags=_lib.FLAG_DECODE_GROUP8 if args.coresident else 0,
-                              decode_priority=args.decode_priority, encoder_streams=args.pipe_encoders or 1)
+                              decode_priority=args.decode_priority, encoder_streams=args.pipe_encoders or 1,
+                              encoder_priority=args.encoder_priority)
 
         def pipe_step():
             if pipe.pending() >= pipe.depth:

@@ -27,7 +27,8 @@ class GreedyPipeline:
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
-                 decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1):
+                 decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1,
+                 encoder_priority: int = 0):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -36,7 +37,7 @@ class GreedyPipeline:
         self.device = dev
         # several encoder streams (round robin): the encoders of consecutive batches run side by side, each one's launch
         # gaps and tile tails filled by the other's workgroups (pays for the 53-launch ResNet trunk)
-        self.enc_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, encoder_streams))]
+        self.enc_streams = [torch.cuda.Stream(device=dev, priority=int(encoder_priority)) for _ in range(max(1, encoder_streams))]
         self._next_enc = 0
         # several decode streams (round robin) let decodes of consecutive batches run side by side, each on
         # few CUs (more rows per workgroup = less weight traffic per row); depth must cover them
