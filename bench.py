@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--dp-single-allreduce", action="store_true",
                     help="--mode train: ONE all-reduce of the flat gradient buffer after the backward pass instead of the "
                          "default two pieces (same sums), the first of which overlaps the conv backward")
+    ap.add_argument("--no-side-wgrad", action="store_true",
+                    help="--mode train: keep the weight-gradient kernels on the step's own stream (default: library side stream)")
     ap.add_argument("--launch-probe", action="store_true",
                     help="rendezvous check only (CPU, gloo): every rank all-reduces its rank number, rank 0 prints "
                          "{n_gpus, ranks_seen}; exercises the self-launch path of `--gpus N` without a GPU")
@@ -759,7 +761,7 @@ def extra_modes(args, world, rank, dev, dist):
         model.load_state_dict({k_: torch.from_numpy(v) for k_, v in synth.make_state_dict(cfg, seed=42).items()})
         model = model.to(dev).train()
         from img2latex_amd.training import TrainStep
-        ts = TrainStep(model, seed=1, overlap_all_reduce=not args.dp_single_allreduce)
+        ts = TrainStep(model, seed=1, overlap_all_reduce=not args.dp_single_allreduce, side_wgrad=not args.no_side_wgrad)
         images = torch.from_numpy(synth.make_images(Bt, cfg, seed=1234 + rank)).to(dev)
         forms = torch.from_numpy(synth.make_formulas(Bt, T, cfg["vocab_size"], seed=777 + rank)).to(torch.int32).to(dev)
 

@@ -653,6 +653,16 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         I2L_CHECK_LAUNCH();
     }
     if (B > 65535) return I2L_ERR_UNSUPPORTED;
+    // I2L_FLAG_SIDE_WGRAD: bias sums and the weight-gradient GEMM(s) leave the caller's stream here (their inputs -- dy,
+    // y, x and the un-pooled gradient -- are complete on it); the data-gradient conv below stays on it.  The two use
+    // disjoint workspace regions (psum / colT / gemm against wpack).
+    hipStream_t sd = s;
+    if (flags & I2L_FLAG_SIDE_WGRAD) {
+        hipStream_t f = i2l_side_fork(s);
+        if (f) sd = f;
+    }
+    const hipStream_t s_main = s;
+    s = sd;
     double* psum = reinterpret_cast<double*>(base + lo.psum);
     hipLaunchKernelGGL(plane_sum_pooled_kernel, dim3(Cout, B), dim3(256), 0, s, dy, y, psum, B, Cout, (size_t)Hp * Wp);
     I2L_CHECK_LAUNCH();
@@ -699,6 +709,7 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         const int rc = i2l_gemm(g, base + lo.gemm, lo.gemm_bytes, s);
         if (rc != I2L_OK) return rc;
     }
+    s = s_main;
     if (dx) {   // data gradient = conv3x3(dyp, flipped / transposed filter), Cout -> Cin channels
         const int rc = run_conv(false, dyp, w, nullptr, dx, nullptr, B, Cout, H, W, Cin, base + lo.wpack, lo.wpack_bytes, s,
                                 exact);

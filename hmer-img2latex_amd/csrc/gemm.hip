@@ -650,7 +650,7 @@ size_t lin_bwd_gemm_ws(int M, int K, int N) {
 
 extern "C" size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    return i2l_align((size_t)M * N * sizeof(float)) + lin_bwd_gemm_ws(M, K, N);
+    return i2l_align((size_t)M * N * sizeof(float)) + 2 * lin_bwd_gemm_ws(M, K, N);   // one GEMM workspace per stream
 }
 
 extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
@@ -671,6 +671,13 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
         I2L_CHECK_LAUNCH();
         d = dpre;
     }
+    // I2L_FLAG_SIDE_WGRAD: db and dw on the library's side stream (own GEMM workspace), dx stays on the caller's
+    hipStream_t s_main = s;
+    char* gws_main = gws;
+    if ((flags & I2L_FLAG_SIDE_WGRAD) && dx) {
+        hipStream_t f = i2l_side_fork(s);
+        if (f) { s = f; gws = gws + gws_bytes; }
+    }
     if (db) {
         hipLaunchKernelGGL(colsum_small_kernel, dim3(i2l_cdiv(N, 32)), dim3(256), 0, s, d, M, N, db);
         I2L_CHECK_LAUNCH();
@@ -685,6 +692,8 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
         const int rc = i2l_gemm(g, gws, gws_bytes, s);
         if (rc != I2L_OK) return rc;
     }
+    s = s_main;
+    gws = gws_main;
     if (dx) {   // dx[m][k] = sum_n d[m][n] * w[n][k]
         GemmArgs g = gemm_args();
         g.split_bf16 = (flags & I2L_FLAG_EXACT_FP32) ? 0 : 1;

@@ -569,7 +569,7 @@ __global__ void bias_gate_kernel(const float* __restrict__ b_ih, const float* __
 // ------------------------------------------------------------------ workspace layout
 struct TLayout {
     size_t X, GX, WhhT[MAXL], WihT[MAXL], biasP[MAXL], ACT[MAXL], C[MAXL], Hout[MAXL], Hprev[MAXL], Hdrop, DG[MAXL],
-        dHdrop, dX, row_loss, row_keep, colpart, gemm_ws, xchg, total;
+        dHdrop, dX, row_loss, row_keep, colpart, colpart2, gemm_ws, gemm_ws2, xchg, total;
     size_t gemm_ws_bytes, xchg_bytes;
     int n_groups;
 };
@@ -593,6 +593,7 @@ TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
     o.row_loss = take(BT);
     o.row_keep = take(BT);
     o.colpart = take((size_t)1024 * (G > (size_t)V ? G : V));
+    o.colpart2 = take((size_t)1024 * (G > (size_t)V ? G : V));      // the side stream's (I2L_FLAG_SIDE_WGRAD)
     size_t g = 0;
     auto mx = [&](size_t v) { if (v > g) g = v; };
     mx(i2l_gemm_workspace_bytes((int)BT, (int)G, 2 * E));     // GX
@@ -604,6 +605,8 @@ TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
     mx(i2l_gemm_workspace_bytes((int)BT, 2 * E, (int)G));     // dX
     o.gemm_ws = off;
     o.gemm_ws_bytes = i2l_align(g);
+    off += o.gemm_ws_bytes;
+    o.gemm_ws2 = off;                                                // the side stream's
     off += o.gemm_ws_bytes;
     if (L == 1 && H == 256) {           // grouped recurrences (train_group.inc.h): status block + exchange granules
         // rows per group: 1 up to 64 rows (all 256 CUs on a 64-row shard), 2 up to 128 rows, 4 above
@@ -804,6 +807,17 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     const size_t BT = (size_t)B * T;
     const int G = 4 * H;
     void* gws = base + lo.gemm_ws;
+    // I2L_FLAG_SIDE_WGRAD (single layer): the weight gradients and bias sums run on the library's side stream with their
+    // own GEMM workspace and column-sum scratch -- dW_out / db_out from here on, dW_ih / dW_hh / db once the recurrence's
+    // backward (on the caller's stream) has produced the gate gradients.  The caller joins (i2l_side_stream_join).
+    hipStream_t s_w = s;
+    void* gws_w = gws;
+    float* colpart_w = F(lo.colpart);
+    const bool side = (flags & I2L_FLAG_SIDE_WGRAD) && L == 1;
+    if (side) {
+        hipStream_t f = i2l_side_fork(s);
+        if (f) { s_w = f; gws_w = base + lo.gemm_ws2; colpart_w = F(lo.colpart2); }
+    }
 
     {   // dW_out[v][h] = sum_bt dlogits[bt][v] * Hdrop[bt][h]
         GemmArgs g = gemm_args();
@@ -812,10 +826,10 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         g.W = F(lo.Hdrop); g.ldw = H; g.w_kc = 0;
         g.C = gr->w_out; g.ldc = H;
         g.M = V; g.N = H; g.K = (int)BT;
-        rc = i2l_gemm(g, gws, lo.gemm_ws_bytes, s);
+        rc = i2l_gemm(g, gws_w, lo.gemm_ws_bytes, s_w);
         if (rc != I2L_OK) return rc;
     }
-    rc = colsum(dlogits, BT, V, F(lo.colpart), gr->b_out, nullptr, s);
+    rc = colsum(dlogits, BT, V, colpart_w, gr->b_out, nullptr, s_w);
     if (rc != I2L_OK) return rc;
     {   // dHdrop[bt][h] = sum_v dlogits[bt][v] * W_out[v][h]
         GemmArgs g = gemm_args();
@@ -881,6 +895,11 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         I2L_CHECK_LAUNCH();
     }
     // weight gradients: one GEMM each over all B*T rows
+    if (side && s_w != s) {                                  // the gate gradients are complete on the caller's stream here
+        hipStream_t f = i2l_side_fork(s);
+        if (!f) return I2L_ERR_LAUNCH;
+        s_w = f;
+    }
     for (int l = 0; l < L; ++l) {
         const float* DGl = F(lo.DG[l]);
         {   // dW_ih_l[n][k] = sum_bt DG[bt][n] * In[bt][k]
@@ -900,7 +919,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
                 I2L_CHECK_LAUNCH();
                 g.W = F(lo.dX);
             }
-            rc = i2l_gemm(g, gws, lo.gemm_ws_bytes, s);
+            rc = i2l_gemm(g, gws_w, lo.gemm_ws_bytes, s_w);
             if (rc != I2L_OK) return rc;
         }
         {   // dW_hh_l[n][k] = sum_bt DG[bt][n] * h_{t-1}[bt][k]
@@ -910,10 +929,10 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
             g.W = F(lo.Hprev[l]); g.ldw = H; g.w_kc = 0;
             g.C = gr->w_hh[l]; g.ldc = H;
             g.M = G; g.N = H; g.K = (int)BT;
-            rc = i2l_gemm(g, gws, lo.gemm_ws_bytes, s);
+            rc = i2l_gemm(g, gws_w, lo.gemm_ws_bytes, s_w);
             if (rc != I2L_OK) return rc;
         }
-        rc = colsum(DGl, BT, G, F(lo.colpart), gr->b_ih[l], gr->b_hh[l], s);
+        rc = colsum(DGl, BT, G, colpart_w, gr->b_ih[l], gr->b_hh[l], s_w);
         if (rc != I2L_OK) return rc;
     }
     {   // dX[bt][k] = sum_n DG0[bt][n] * W_ih_0[n][k]

@@ -25,7 +25,7 @@ from .dp import OverlappedAllReduce, broadcast_parameters, rank_of
 class TrainStep:
     def __init__(self, model, lr: float = 1e-3, weight_decay: float = 1e-4, clip_grad_norm: float = 5.0,
                  pad_token_id: int = 0, label_smoothing: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, seed: int = 0, overlap_all_reduce: bool = True):
+                 process_group=None, seed: int = 0, overlap_all_reduce: bool = True, side_wgrad: bool = True):
         self.model = model
         self.lr, self.weight_decay, self.clip = lr, weight_decay, clip_grad_norm
         self.pad, self.smoothing, self.betas, self.eps = pad_token_id, label_smoothing, betas, eps
@@ -74,6 +74,10 @@ class TrainStep:
         # north_star's wording); True (default): the same element-wise sums issued in two pieces, the first -- everything
         # but the conv gradients -- as soon as the FC backward is enqueued, beside ~1 ms of conv backward (dp.py)
         self.overlap_all_reduce = bool(overlap_all_reduce)
+        # weight gradients on the library's side stream beside the data-gradient chain (csrc/api.hip, I2L_FLAG_SIDE_WGRAD);
+        # False keeps the whole backward on one stream (same kernels, same sums either way)
+        self.side_wgrad = bool(side_wgrad)
+        self._side_keep = []          # buffers the side stream's kernels still read; released after the join
         self._reducer = OverlappedAllReduce(self.flat_grads, self.n_early, self.group)
         L = _lib.lib()
         # zeroed once: besides scratch it carries the count of skipped (non-finite) updates across calls
@@ -103,16 +107,41 @@ class TrainStep:
                                                  self.flat_grads.data_ptr() + 4 * self.n, _lib.stream_ptr()),
                    "ce_label_smooth_fwd_bwd")
         dgr = {n[len("decoder."):]: g for n, g in self.grad_views.items() if n.startswith("decoder.")}
-        denc = decoder_train_backward(model.decoder, dec_state, dlogits, dgr)
+        # weight gradients feed nothing in the backward chain: they go to the library's side stream (FLAG_SIDE_WGRAD) and
+        # fill the launch gaps and tile tails of the data-gradient chain; the join at the end of this method orders them
+        # before the all-reduce / Adam.
+        # Everything those kernels read is held in _side_keep until then.
+        side = _lib.FLAG_SIDE_WGRAD if self.side_wgrad else 0
+        self._join_side()                                            # a previous forward_backward() without apply()
+        denc = decoder_train_backward(model.decoder, dec_state, dlogits, dgr, extra_flags=side)
+        if side:
+            self._side_keep.extend((dec_state, dlogits, enc_state, images, tokens_in))
         egr = {n[len("encoder."):]: g for n, g in self.grad_views.items() if n.startswith("encoder.")}
-        # decoder + FC gradients are final once the FC backward is enqueued: their all-reduce starts there
+
+        def after_linear():
+            # decoder + FC gradients are final once the FC backward is enqueued -- and, with side-stream weight
+            # gradients, joined: their all-reduce starts there
+            if self._reducer._active():
+                self._join_side(clear=False)
+            self._reducer.start_early()
         encoder_train_backward(model.encoder, enc_state, denc, egr,
-                               after_linear=self._reducer.start_early if self.overlap_all_reduce else None)
+                               after_linear=after_linear if self.overlap_all_reduce else None, extra_flags=side,
+                               keep=self._side_keep)
+        self._join_side()          # flat_grads is complete for whatever the current stream does next (all-reduce, Adam, a reader)
         return logits
+
+    def _join_side(self, clear: bool = True) -> None:
+        """The current stream waits for the side stream's weight gradients (no-op when none are pending)."""
+        if self._side_keep:
+            _lib.check(_lib.lib().i2l_side_stream_join(_lib.stream_ptr()), "side_stream_join")
+            if clear:
+                # the buffers may be reused by later work on this stream only: that work is ordered after the join
+                self._side_keep = []
 
     def apply(self) -> None:
         """All-reduce (data parallel), then clip + Adam; bumps the step counter."""
         L = _lib.lib()
+        self._join_side()
         self._reducer.finish()
         self.step_count += 1
         _lib.check(L.i2l_grad_clip_adam_step(

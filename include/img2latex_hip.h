@@ -66,10 +66,21 @@ typedef void* i2l_stream_t;
                                           with EIGHT members x EIGHT rows per group -- one wave per SIMD and ~80 KB of LDS
                                           per CU instead of two waves and 140 KB, so that a conv workgroup of the NEXT
                                           batch's encoder fits beside it; same ids                                   */
+#define I2L_FLAG_SIDE_WGRAD 0x2000     /* i2l_decoder_train_bwd, i2l_linear_bias_act_bwd, i2l_conv3x3_relu_pool2_bwd: the WEIGHT
+                                          gradients (and bias sums) are enqueued on the library's side stream, forked from
+                                          `stream` where their inputs are ready, beside the data-gradient chain that stays
+                                          on `stream`.  The caller must call i2l_side_stream_join(stream) before anything
+                                          reads those gradients, and keep every buffer passed to the call (workspace,
+                                          activations, dy) alive until then.  Same kernels, same sums: results identical */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
 
 int i2l_version(void);
 const char* i2l_error_string(int code);
+/* Makes `stream` wait for everything the backward entry points enqueued on the library's side stream under
+ * I2L_FLAG_SIDE_WGRAD (a no-op when nothing was).  The reference has no counterpart: its autograd engine orders
+ * `loss.backward()` (trainer.py:337) before `optimizer.step()` (trainer.py:343) by itself; here the caller of the
+ * backward entry points states that order once per step. */
+int i2l_side_stream_join(i2l_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Encoder (reference img2latex/model/encoder.py)

@@ -360,6 +360,34 @@ def test_train_step_loss_decreases_and_dropout_runs():
     assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses[::5]
 
 
+def test_side_stream_weight_gradients_are_the_same_numbers():
+    """I2L_FLAG_SIDE_WGRAD moves the weight-gradient kernels to the library's side stream: same kernels, same sums, so every
+    gradient is bit-identical with and without it (primary dims, 64 x 21) -- except the embedding rows, whose scatter adds
+    with atomics in an order that varies from launch to launch on ONE stream as well (compared to 1e-6 of the largest)."""
+    from img2latex_amd.training import TrainStep
+    runs = []
+    for side in (True, False):
+        _, cfg, m = build("primary")
+        m.train()
+        ts = TrainStep(m, seed=3, side_wgrad=side)
+        x = images(cfg, batch=64, seed=61, device=DEV)
+        forms = torch.from_numpy(synth.make_formulas(64, 22, cfg["vocab_size"], seed=62, min_len=5)).to(DEV)
+        ts.forward_backward(x, forms)
+        assert not ts._side_keep                               # joined and released
+        torch.cuda.synchronize()
+        runs.append((ts, ts.flat_grads.clone()))
+    ts, a = runs[0]
+    b = runs[1][1]
+    sizes = {n: p.numel() for n, p in ts.model.named_parameters()}
+    for name, off in ts.offsets.items():
+        ga, gb = a[off:off + sizes[name]], b[off:off + sizes[name]]
+        if name == "decoder.embedding.weight":
+            assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max())
+        else:
+            assert torch.equal(ga, gb), name
+    assert torch.equal(a[ts.n:ts.n + 2], b[ts.n:ts.n + 2])      # loss sum, token count
+
+
 def test_data_parallel_shards_equal_full_batch():
     """SURVEY 8e parity for the DP step, emulated in one process: two ranks' flat buffers are summed
     (what the RCCL all-reduce does), then every rank applies clip + Adam with the GLOBAL count; the
