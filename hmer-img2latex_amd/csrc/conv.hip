@@ -578,9 +578,224 @@ __global__ void plane_sum_final_kernel(const double* __restrict__ partial, float
     db[c] = (float)s;
 }
 
+
+// ---- weight + bias gradient of the FIRST block (no data gradient wanted, Cin <= 3): the sparse form --------------------
+// Max-pooling sends each pooled gradient to ONE of its four positions, so dW[co][ci][ky][kx] needs one product per pooled
+// cell, channel and tap -- a quarter of what the implicit-im2col GEMM over the un-pooled gradient multiplies, and at
+// Cout x 27 outputs that GEMM wastes most of its 128 x 64 tile besides.  Exact fp32 on the vector ALUs:
+//   workgroup = (image, band of FB_PB pooled rows, block of 32 output channels); the band's input rows (+ halo, zero padded)
+//   and its masked gradients / arg-max codes sit in LDS; thread (co = tid & 31, grp = tid >> 5) walks cells grp, grp + 8, ..
+//   with its Cin x 9 sums in registers (the four arg-max variants of a cell's window land in four different banks, the
+//   gradient rows have an odd stride); the 8 groups are summed in a fixed order and every workgroup writes its partial
+//   [32][Cin*9 + 1] (last = bias); conv_wgrad_first_reduce_kernel adds the partials in double, in a fixed order.
+constexpr int FB_PB = 1;
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_wgrad_first_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ y,
+                                                               const unsigned char* __restrict__ amax,
+                                                               float* __restrict__ partial, int H, int W, int Cout, int Hp,
+                                                               int Wp, int bands, int fast) {
+    constexpr int K9 = CIN * 9, XR = 2 * FB_PB + 2, NO = K9 + 1;
+    extern __shared__ __attribute__((aligned(16))) float fb_sm[];
+    const int XW = W + 2, NC = FB_PB * Wp, GS = NC | 1;
+    float* x_s = fb_sm;                                         // [CIN][XR][XW], column 0 = image column -1
+    float* g_s = x_s + CIN * XR * XW;                           // [32][GS] masked pooled gradient; later the group sums
+    unsigned char* a_s = reinterpret_cast<unsigned char*>(g_s + (32 * GS > 8 * 32 * NO ? 32 * GS : 8 * 32 * NO));
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / bands, band = blockIdx.x - b * bands, cb = blockIdx.y;
+    const int p0 = band * FB_PB, r0 = 2 * p0 - 1;
+    // staging.  Fast path (W % 8 == 0, W <= 512, 16-byte aligned tensors; FB_PB == 1): whole rows as 16-byte pieces, every
+    // global load of the workgroup issued before the first LDS store -- thread (row = tid >> 3, seg = tid & 7) takes pieces
+    // seg, seg + 8, .. of gradient row `row` (y, dy: float4, arg max: 4 codes), thread (xr = tid >> 4, xs = tid & 15) pieces
+    // xs, xs + 16, .. of window row xr; all loads unconditional from clamped addresses, masks applied at the store
+    const int n_x = CIN * XR * XW, n_g = 32 * NC;
+    if (fast) {
+        constexpr int KG = 8, KX = 8;
+        const int grow = tid >> 3, seg = tid & 7, nq = Wp >> 2;
+        const int cog = cb * 32 + grow;
+        const bool gvalid = p0 < Hp && cog < Cout;
+        const size_t orow = (((size_t)b * Cout + min(cog, Cout - 1)) * Hp + min(p0, Hp - 1)) * Wp;
+        const float4* y4 = reinterpret_cast<const float4*>(y + orow);
+        const float4* d4 = reinterpret_cast<const float4*>(dy + orow);
+        const unsigned* a4 = reinterpret_cast<const unsigned*>(amax + orow);
+        const int xr = tid >> 4, xs = tid & 15, nxq = W >> 2;
+        const int xci = min(xr / XR, CIN - 1), xrr = xr - (xr / XR) * XR, Y = r0 + xrr;
+        const bool xvalid = xr < CIN * XR && (unsigned)Y < (unsigned)H;
+        const float4* x4 = reinterpret_cast<const float4*>(x + (((size_t)b * CIN + xci) * H + min(max(Y, 0), H - 1)) * W);
+        float4 vy[KG], vd[KG], vx[KX];
+        unsigned va[KG];
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            const int q = min(seg + 8 * k, nq - 1);
+            vy[k] = y4[q];
+            vd[k] = d4[q];
+            va[k] = a4[q];
+        }
+#pragma unroll
+        for (int k = 0; k < KX; ++k) vx[k] = x4[min(xs + 16 * k, nxq - 1)];
+        if (xr < CIN * XR) {
+            float* xrow = x_s + xr * XW;
+            if (xs == 0) xrow[0] = 0.f;
+            if (xs == 1) xrow[W + 1] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KX; ++k) {
+                const int q = xs + 16 * k;
+                if (q < nxq) {
+                    xrow[1 + 4 * q] = xvalid ? vx[k].x : 0.f;
+                    xrow[2 + 4 * q] = xvalid ? vx[k].y : 0.f;
+                    xrow[3 + 4 * q] = xvalid ? vx[k].z : 0.f;
+                    xrow[4 + 4 * q] = xvalid ? vx[k].w : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            const int q = seg + 8 * k;
+            if (q < nq) {
+                float* gr = g_s + grow * GS + 4 * q;
+                unsigned char* ar = a_s + grow * GS + 4 * q;
+                gr[0] = gvalid && vy[k].x > 0.f ? vd[k].x : 0.f;
+                gr[1] = gvalid && vy[k].y > 0.f ? vd[k].y : 0.f;
+                gr[2] = gvalid && vy[k].z > 0.f ? vd[k].z : 0.f;
+                gr[3] = gvalid && vy[k].w > 0.f ? vd[k].w : 0.f;
+                ar[0] = gvalid ? (unsigned char)(va[k] & 0xFF) : (unsigned char)0;
+                ar[1] = gvalid ? (unsigned char)((va[k] >> 8) & 0xFF) : (unsigned char)0;
+                ar[2] = gvalid ? (unsigned char)((va[k] >> 16) & 0xFF) : (unsigned char)0;
+                ar[3] = gvalid ? (unsigned char)(va[k] >> 24) : (unsigned char)0;
+            }
+        }
+    } else {
+        // any other shape: element by element, batches of 8 loads per thread
+        for (int base0 = 0; base0 < n_x; base0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base0 + u * 256 + tid;
+                const int ci = idx / (XR * XW), rem = idx - ci * XR * XW;
+                const int rr = rem / XW, cc = rem - rr * XW;
+                const int Y = r0 + rr, X = cc - 1;
+                const bool in = idx < n_x && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+                const int cic = ci < CIN ? ci : CIN - 1, Yc = min(max(Y, 0), H - 1), Xc = min(max(X, 0), W - 1);
+                const float t = x[(((size_t)b * CIN + cic) * H + Yc) * W + Xc];
+                v[u] = in ? t : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base0 + u * 256 + tid < n_x) x_s[base0 + u * 256 + tid] = v[u];
+        }
+        for (int base0 = 0; base0 < n_g; base0 += 8 * 256) {
+            float gy[8], gd[8];
+            unsigned char ga[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base0 + u * 256 + tid;
+                const int co = idx / NC, c = idx - co * NC;
+                const int pr = c / Wp, px = c - pr * Wp, P = p0 + pr, cog = cb * 32 + co;
+                const bool in = idx < n_g && P < Hp && cog < Cout;
+                const size_t o = (((size_t)b * Cout + min(cog, Cout - 1)) * Hp + min(P, Hp - 1)) * Wp + px;   // always valid
+                const float ty = y[o], td = dy[o];
+                const unsigned char ta = amax[o];
+                gy[u] = in && ty > 0.f ? td : 0.f;
+                gd[u] = 0.f;
+                ga[u] = in ? ta : (unsigned char)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base0 + u * 256 + tid;
+                if (idx < n_g) {
+                    const int co = idx / NC, c = idx - co * NC;
+                    g_s[co * GS + c] = gy[u];
+                    a_s[co * GS + c] = ga[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int co = tid & 31, grp = tid >> 5;
+    float acc[K9], accb = 0.f;
+#pragma unroll
+    for (int j = 0; j < K9; ++j) acc[j] = 0.f;
+    int pr = 0, px = grp;
+    while (px >= Wp) { px -= Wp; ++pr; }
+    for (int c = grp; c < NC; c += 8) {
+        const float g = g_s[co * GS + c];
+        const int a = a_s[co * GS + c];
+        const float* xw = x_s + (2 * pr + (a >> 1)) * XW + 2 * px + (a & 1);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ci * 9 + ky * 3 + kx] = fmaf(g, xw[(ci * XR + ky) * XW + kx], acc[ci * 9 + ky * 3 + kx]);
+        accb += g;
+        px += 8;
+        while (px >= Wp) { px -= Wp; ++pr; }
+    }
+    __syncthreads();                                            // everyone is done with g_s: it becomes the group sums
+    float* red = g_s;
+#pragma unroll
+    for (int j = 0; j < K9; ++j) red[(grp * 32 + co) * NO + j] = acc[j];
+    red[(grp * 32 + co) * NO + K9] = accb;
+    __syncthreads();
+    float* out = partial + ((size_t)blockIdx.x * gridDim.y + cb) * (32 * NO);
+    for (int o = tid; o < 32 * NO; o += 256) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) sum += red[g8 * 32 * NO + o];
+        out[o] = sum;
+    }
+}
+
+// dw[co][j] (j < K9) and db[co] (j == K9) = sum over the n_wg partials, 8 outputs x 32 slices per workgroup, in double
+__global__ __launch_bounds__(256) void conv_wgrad_first_reduce_kernel(const float* __restrict__ partial, int n_wg, int co_blocks,
+                                                                      int K9, int Cout, float* __restrict__ dw,
+                                                                      float* __restrict__ db) {
+    __shared__ double red[32][9];
+    const int NO = K9 + 1, per_cb = 32 * NO, n_out = co_blocks * per_cb;
+    const int ol = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int o = blockIdx.x * 8 + ol;
+    const int cb = o < n_out ? o / per_cb : 0, r = o - cb * per_cb;
+    double s = 0.0;
+    if (o < n_out) {
+        const float* src = partial + (size_t)cb * per_cb + r;
+        const size_t step = (size_t)co_blocks * per_cb;
+        int wgi = sl;
+        for (; wgi + 7 * 32 < n_wg; wgi += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(wgi + 32 * u) * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; wgi < n_wg; wgi += 32) s += (double)src[(size_t)wgi * step];
+    }
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && o < n_out) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][ol];
+        const int co = cb * 32 + r / NO, j = r - (r / NO) * NO;
+        if (co < Cout) {
+            if (j < K9) dw[(size_t)co * K9 + j] = (float)t;
+            else db[co] = (float)t;
+        }
+    }
+}
+
 constexpr int WG_CHUNK = 32;    // images per weight-gradient GEMM call
 
-struct BwdLayout { size_t dyp, colT, gemm, wpack, psum, total; size_t gemm_bytes, wpack_bytes; int chunk; };
+struct BwdLayout { size_t dyp, colT, gemm, wpack, psum, first, total; size_t gemm_bytes, wpack_bytes, first_bytes; int chunk; };
+
+// conv_wgrad_first_kernel: LDS bytes for this width, 0 when the shape is not its business
+size_t wgrad_first_lds(int Cin, int W, int Cout) {
+    if (Cin < 1 || Cin > 3 || Cout % 32 != 0 || W < 2) return 0;
+    const int Wp = W / 2, NC = FB_PB * Wp, GS = NC | 1, NO = Cin * 9 + 1;
+    const size_t gs = (size_t)(32 * GS > 8 * 32 * NO ? 32 * GS : 8 * 32 * NO);
+    const size_t b = ((size_t)Cin * (2 * FB_PB + 2) * (W + 2) + gs) * sizeof(float) + (size_t)32 * GS;
+    return b <= 80 * 1024 ? b : 0;
+}
 
 BwdLayout bwd_layout(int B, int Cin, int H, int W, int Cout) {
     BwdLayout o{};
@@ -598,6 +813,10 @@ BwdLayout bwd_layout(int B, int Cin, int H, int W, int Cout) {
     o.wpack_bytes = i2l_conv_workspace_bytes(Cout, Cin);         // data-gradient conv: Cout -> Cin channels
     o.wpack = off; off += i2l_align(o.wpack_bytes);
     o.psum = off; off += i2l_align((size_t)B * Cout * sizeof(double));
+    if (wgrad_first_lds(Cin, W, Cout)) {         // partial sums of the first block's sparse weight-gradient kernel
+        o.first_bytes = (size_t)B * i2l_cdiv(H / 2, FB_PB) * (Cout / 32) * 32 * (Cin * 9 + 1) * sizeof(float);
+        o.first = off; off += i2l_align(o.first_bytes);
+    }
     o.total = off;
     return o;
 }
@@ -636,8 +855,10 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     gp.split_bf16 = split;
     gp.C = dw; gp.ldc = Cin * 9;
     gp.M = Cout; gp.N = Cin * 9; gp.K = (int)HW;
+    const size_t first_lds = (dx || (flags & I2L_FLAG_CONV_NO_SPARSE_WGRAD) || Hp < 1 || Wp < 1 || !lo.first_bytes)
+                                 ? 0 : wgrad_first_lds(Cin, W, Cout);      // the sparse first-block kernel reads dy itself
     const bool fused_unpool = !dx && (H % 2) == 0 && (W % 2) == 0 && i2l_gemm_split_bf16_ok(gp);
-    if (!fused_unpool) {
+    if (!fused_unpool && !first_lds) {
         const size_t total = (size_t)B * Cout * HW;
         size_t blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
@@ -663,6 +884,35 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     }
     const hipStream_t s_main = s;
     s = sd;
+    if (first_lds) {
+        const int bands = i2l_cdiv(Hp, FB_PB), cbs = Cout / 32;
+        auto al = [](const void* q, uintptr_t a) { return reinterpret_cast<uintptr_t>(q) % a == 0; };
+        const int fast = (FB_PB == 1 && W % 8 == 0 && W <= 512 && al(x, 16) && al(y, 16) && al(dy, 16) && al(argmax, 4)) ? 1 : 0;
+        float* part = reinterpret_cast<float*>(base + lo.first);
+        dim3 grid((unsigned)(B * bands), (unsigned)cbs);
+#define I2L_FIRST(CI)                                                                                                  \
+        do {                                                                                                           \
+            static bool attr_done = false;                                                                             \
+            if (!attr_done) {                                                                                          \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_first_kernel<CI>),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)         \
+                    return I2L_ERR_LAUNCH;                                                                             \
+                attr_done = true;                                                                                      \
+            }                                                                                                          \
+            hipLaunchKernelGGL(conv_wgrad_first_kernel<CI>, grid, dim3(256), first_lds, s, x, dy, y, argmax, part, H, W, \
+                               Cout, Hp, Wp, bands, fast);                                                                 \
+        } while (0)
+        if (Cin == 1) I2L_FIRST(1);
+        else if (Cin == 2) I2L_FIRST(2);
+        else I2L_FIRST(3);
+#undef I2L_FIRST
+        I2L_CHECK_LAUNCH();
+        const int n_out = cbs * 32 * (Cin * 9 + 1);
+        hipLaunchKernelGGL(conv_wgrad_first_reduce_kernel, dim3(i2l_cdiv(n_out, 8)), dim3(256), 0, s, (const float*)part,
+                           B * bands, cbs, Cin * 9, Cout, dw, db);
+        I2L_CHECK_LAUNCH();
+        return I2L_OK;
+    }
     double* psum = reinterpret_cast<double*>(base + lo.psum);
     hipLaunchKernelGGL(plane_sum_pooled_kernel, dim3(Cout, B), dim3(256), 0, s, dy, y, psum, B, Cout, (size_t)Hp * Wp);
     I2L_CHECK_LAUNCH();

@@ -24,6 +24,7 @@ MAX_LSTM_LAYERS, MAX_BEAM = 4, 8
 FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0x1, 0x2, 0x4, 0x8
 FLAG_WEIGHTS_PACKED = 0x10          # conv forward: the workspace still holds the packed filters of these weights
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
+FLAG_CONV_NO_SPARSE_WGRAD = 0x4000   # first conv block's weight gradient by the implicit-im2col GEMM (A/B)
 FLAG_SIDE_WGRAD = 0x2000             # training backward: weight gradients on the library's side stream (join before use)
 FLAG_DECODE_GROUP8 = 0x1000          # greedy decode: 8 members x 8 rows per group (co-resident with a conv workgroup)
 FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks of the grouped kernels

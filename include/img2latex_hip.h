@@ -66,6 +66,8 @@ typedef void* i2l_stream_t;
                                           with EIGHT members x EIGHT rows per group -- one wave per SIMD and ~80 KB of LDS
                                           per CU instead of two waves and 140 KB, so that a conv workgroup of the NEXT
                                           batch's encoder fits beside it; same ids                                   */
+#define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
+                                          implicit-im2col GEMM instead of the sparse first-block kernel (A/B, tests)   */
 #define I2L_FLAG_SIDE_WGRAD 0x2000     /* i2l_decoder_train_bwd, i2l_linear_bias_act_bwd, i2l_conv3x3_relu_pool2_bwd: the WEIGHT
                                           gradients (and bias sums) are enqueued on the library's side stream, forked from
                                           `stream` where their inputs are ready, beside the data-gradient chain that stays

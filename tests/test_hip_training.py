@@ -259,6 +259,51 @@ def test_conv_bwd_odd_shapes():
         rel_close(db.cpu().numpy(), b.grad.numpy(), 2e-4, "db")
 
 
+def test_first_block_sparse_weight_gradient():
+    """dx == NULL, Cin <= 3, Cout % 32 == 0: conv_wgrad_first_kernel (one product per pooled cell, channel and tap, exact fp32)
+    against autograd in float64 and against the implicit-im2col GEMM it replaces (FLAG_CONV_NO_SPARSE_WGRAD); odd heights /
+    widths (the last row / column is outside every pooling window), one and two channel blocks, a band that ends past the
+    last pooled row."""
+    torch.manual_seed(4)
+    L = _lib.lib()
+    for (B, Cin, H, W, Cout) in [(3, 3, 64, 320, 32), (2, 1, 16, 36, 32), (2, 3, 17, 33, 64), (5, 2, 6, 10, 32),
+                                 (1, 3, 2, 2, 32), (2, 1, 64, 800, 32)]:
+        x = torch.randn(B, Cin, H, W, dtype=torch.float64)
+        w = (torch.randn(Cout, Cin, 3, 3, dtype=torch.float64) / (3 * Cin ** 0.5)).requires_grad_(True)
+        b = torch.randn(Cout, dtype=torch.float64, requires_grad=True)
+        xd, wd, bd = x.float().to(DEV), w.detach().float().to(DEV), b.detach().float().to(DEV)
+        yd = torch.empty((B, Cout, H // 2, W // 2), device=DEV)
+        am = torch.empty(yd.shape, dtype=torch.uint8, device=DEV)
+        nb = L.i2l_conv_workspace_bytes(Cin, Cout)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+        assert L.i2l_conv3x3_relu_pool2_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), am.data_ptr(), B,
+                                            Cin, H, W, Cout, ws.data_ptr(), nb, 0, _lib.stream_ptr()) == 0
+        dy = torch.randn(yd.shape, dtype=torch.float64)
+        # float64 autograd UNDER THE HIP FORWARD'S decisions (which window position won, which outputs are positive)
+        z = torch.nn.functional.conv2d(x.float().double(), w, b, padding=1)
+        Hp, Wp = H // 2, W // 2
+        zc = z[:, :, :2 * Hp, :2 * Wp].reshape(B, Cout, Hp, 2, Wp, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, Cout, Hp, Wp, 4)
+        pick = torch.gather(zc, 4, am.cpu().long().unsqueeze(-1)).squeeze(-1)
+        mask = (yd.cpu() > 0).double()
+        (pick * mask * dy).sum().backward()
+        dyd = dy.float().to(DEV)
+        nb2 = L.i2l_conv_bwd_workspace_bytes(B, Cin, H, W, Cout)
+        outs = []
+        for fl in (0, _lib.FLAG_CONV_NO_SPARSE_WGRAD):
+            dw = torch.full_like(wd, float("nan"))
+            db = torch.full_like(bd, float("nan"))
+            ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
+            assert L.i2l_conv3x3_relu_pool2_bwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), am.data_ptr(), dyd.data_ptr(),
+                                                None, dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout,
+                                                ws2.data_ptr(), nb2, fl, _lib.stream_ptr()) == 0
+            outs.append((dw.cpu().numpy(), db.cpu().numpy()))
+        tag = f"first-block wgrad {B}x{Cin}x{H}x{W}->{Cout}"
+        rel_close(outs[0][0], w.grad.numpy(), 2e-5, tag + " dw (sparse kernel vs float64)")
+        rel_close(outs[0][1], b.grad.numpy(), 2e-5, tag + " db (sparse kernel vs float64)")
+        rel_close(outs[1][0], w.grad.numpy(), 2e-4, tag + " dw (GEMM vs float64)")
+        rel_close(outs[0][0], outs[1][0], 2e-4, tag + " dw (sparse kernel vs GEMM)")
+
+
 def _params_after_vs_fixture(name, cfg, names, sdict, after, d, x_cpu, forms_cpu, hip_grads):
     """Parameters after the first clip + Adam step.  Adam's first update is lr * x / (|x| + eps) with x = coef * g +
     wd * p0: an element whose |x| ~ eps = 1e-8 -- a tiny gradient, or a clipped gradient that happens to cancel the
