@@ -14,13 +14,15 @@ extern "C" const char* i2l_error_string(int code) {
     }
 }
 
-// ------------------------------------------------------------------ side stream of the training backward pass
+// ------------------------------------------------------------------ side streams of the training backward pass
 // Weight gradients do not feed the backward chain: with I2L_FLAG_SIDE_WGRAD the backward entry points enqueue them on
-// this non-blocking stream (one per device), forked from the caller's stream by an event, so that they fill the launch
+// one of two non-blocking streams per device (lane 0: decoder and FC layer, lane 1: conv blocks -- so that a conv weight
+// gradient does not queue behind the decoder's), forked from the caller's stream by an event, where they fill the launch
 // gaps and tile tails of the data-gradient chain.  i2l_side_stream_join(stream) makes `stream` wait for all of it.
 #include <mutex>
 namespace {
-struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
+constexpr int N_LANES = 2;
+struct Side { hipStream_t s[N_LANES] = {}; hipEvent_t fork[N_LANES] = {}, join[N_LANES] = {}; bool tried = false, ok = false; };
 Side g_side[16];
 std::mutex g_side_mu;
 Side* side_of_current_device() {
@@ -29,28 +31,33 @@ Side* side_of_current_device() {
     Side& sd = g_side[dev];
     if (!sd.tried) {
         sd.tried = true;
-        if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) { sd.s = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) { sd.s = nullptr; return nullptr; }
+        sd.ok = true;
+        for (int i = 0; i < N_LANES; ++i)
+            if (hipStreamCreateWithFlags(&sd.s[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&sd.fork[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&sd.join[i], hipEventDisableTiming) != hipSuccess)
+                sd.ok = false;
     }
-    return sd.s ? &sd : nullptr;
+    return sd.ok ? &sd : nullptr;
 }
 }  // namespace
 
-hipStream_t i2l_side_fork(hipStream_t main) {
+hipStream_t i2l_side_fork(hipStream_t main, int lane) {
     std::lock_guard<std::mutex> lock(g_side_mu);
     Side* sd = side_of_current_device();
-    if (!sd) return nullptr;
-    if (hipEventRecord(sd->fork, main) != hipSuccess) return nullptr;
-    if (hipStreamWaitEvent(sd->s, sd->fork, 0) != hipSuccess) return nullptr;
-    return sd->s;
+    if (!sd || lane < 0 || lane >= N_LANES) return nullptr;
+    if (hipEventRecord(sd->fork[lane], main) != hipSuccess) return nullptr;
+    if (hipStreamWaitEvent(sd->s[lane], sd->fork[lane], 0) != hipSuccess) return nullptr;
+    return sd->s[lane];
 }
 
 extern "C" int i2l_side_stream_join(i2l_stream_t stream) {
     std::lock_guard<std::mutex> lock(g_side_mu);
     Side* sd = side_of_current_device();
     if (!sd) return I2L_OK;                              // nothing was ever forked
-    if (hipEventRecord(sd->join, sd->s) != hipSuccess) return I2L_ERR_LAUNCH;
-    if (hipStreamWaitEvent(i2l_s(stream), sd->join, 0) != hipSuccess) return I2L_ERR_LAUNCH;
+    for (int i = 0; i < N_LANES; ++i) {
+        if (hipEventRecord(sd->join[i], sd->s[i]) != hipSuccess) return I2L_ERR_LAUNCH;
+        if (hipStreamWaitEvent(i2l_s(stream), sd->join[i], 0) != hipSuccess) return I2L_ERR_LAUNCH;
+    }
     return I2L_OK;
 }

@@ -11,9 +11,9 @@
     } while (0)
 
 static inline hipStream_t i2l_s(i2l_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
-// I2L_FLAG_SIDE_WGRAD (api.hip): the library's side stream, made to wait for everything enqueued on `main` so far.
+// I2L_FLAG_SIDE_WGRAD (api.hip): one of the library's side streams, made to wait for everything enqueued on `main` so far.
 // Returns nullptr when it cannot be created (the caller then stays on `main`).  i2l_side_stream_join() is the way back.
-hipStream_t i2l_side_fork(hipStream_t main);
+hipStream_t i2l_side_fork(hipStream_t main, int lane);   // lane 0: decoder + FC weight gradients, lane 1: conv blocks
 static inline int i2l_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t i2l_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

@@ -878,8 +878,8 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
     // y, x and the un-pooled gradient -- are complete on it); the data-gradient conv below stays on it.  The two use
     // disjoint workspace regions (psum / colT / gemm against wpack).
     hipStream_t sd = s;
-    if (flags & I2L_FLAG_SIDE_WGRAD) {
-        hipStream_t f = i2l_side_fork(s);
+    if ((flags & I2L_FLAG_SIDE_WGRAD) && dx) {           // the first block (no dx) has nothing to run beside: it stays here
+        hipStream_t f = i2l_side_fork(s, 1);
         if (f) sd = f;
     }
     const hipStream_t s_main = s;

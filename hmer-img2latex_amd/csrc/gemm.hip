@@ -675,7 +675,7 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
     hipStream_t s_main = s;
     char* gws_main = gws;
     if ((flags & I2L_FLAG_SIDE_WGRAD) && dx) {
-        hipStream_t f = i2l_side_fork(s);
+        hipStream_t f = i2l_side_fork(s, 0);
         if (f) { s = f; gws = gws + gws_bytes; }
     }
     if (db) {

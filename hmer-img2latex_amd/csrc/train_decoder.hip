@@ -815,7 +815,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     float* colpart_w = F(lo.colpart);
     const bool side = (flags & I2L_FLAG_SIDE_WGRAD) && L == 1;
     if (side) {
-        hipStream_t f = i2l_side_fork(s);
+        hipStream_t f = i2l_side_fork(s, 0);
         if (f) { s_w = f; gws_w = base + lo.gemm_ws2; colpart_w = F(lo.colpart2); }
     }
 
@@ -896,7 +896,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     }
     // weight gradients: one GEMM each over all B*T rows
     if (side && s_w != s) {                                  // the gate gradients are complete on the caller's stream here
-        hipStream_t f = i2l_side_fork(s);
+        hipStream_t f = i2l_side_fork(s, 0);
         if (!f) return I2L_ERR_LAUNCH;
         s_w = f;
     }
