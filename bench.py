@@ -791,7 +791,7 @@ def extra_modes(args, world, rank, dev, dist):
             return {"value": round(Bt * (T - 1) / min(ts_), 1), "unit": "tokens/s", "cores": torch.get_num_threads(),
                     "kind": "port", "sample": f"the full per-GPU workload (B={Bt}, T={T - 1}), autograd fwd+bwd+clip+Adam, "
                                               "dropout off, best of 2"}
-        name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "parallelism": f"dp{world}: one flat-buffer all-reduce" + (" (single call)" if args.dp_single_allreduce else " (issued in two pieces, the first beside the conv backward)")}
+        name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "backward_streams": ("1 (--no-side-wgrad)" if args.no_side_wgrad else "3: data-gradient chain on the step's stream, weight gradients on two library side streams (I2L_FLAG_SIDE_WGRAD), joined before clip + Adam"), "parallelism": f"dp{world}: one flat-buffer all-reduce" + (" (single call)" if args.dp_single_allreduce else " (issued in two pieces, the first beside the conv backward)")}
 
     for _ in range(args.warmup):
         one_step()
