@@ -1038,6 +1038,42 @@ def test_coresident_pipeline_ids_vs_reference():
             assert _margin_guard(g[:, :steps], ref_ids, d["margins"], tol=2e-4) <= 0.05 * 256
 
 
+def test_pipeline_with_two_encoder_streams_resnet():
+    """GreedyPipeline(encoder_streams=2): two ResNet trunks in flight beside the decode (bench.py --mode resnet).  Seven
+    batches of three distinct image sets through it: every batch's ids equal the one-batch-at-a-time search on the same
+    kernels' encoder output (the trunk is deterministic per batch, the 8-member decode may differ from the 4-member one only
+    at fp32 near-ties), results come back in submission order, per-stream workspaces do not collide."""
+    from img2latex_amd.model import Seq2SeqModel
+    from img2latex_amd.pipeline import GreedyPipeline
+    cfg = synth.model_config()
+    enc_p = dict(img_height=64, img_width=320, channels=3, model_name="resnet18", embedding_dim=256, freeze_backbone=True)
+    m = Seq2SeqModel("resnet_lstm", cfg["vocab_size"], enc_p, synth.decoder_params(cfg))
+    shapes = [(k, tuple(v.shape)) for k, v in m.encoder.state_dict().items()]
+    full = {"encoder." + k: torch.from_numpy(v) for k, v in synth.make_resnet_state_dict(shapes, seed=5).items()}
+    full.update({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=42, out_scale=8.0).items()
+                 if k.startswith("decoder.")})
+    m.load_state_dict(full)
+    m = m.to(DEV).eval()
+    sets = [torch.from_numpy(synth.make_images(96, cfg, seed=s)).to(DEV) for s in (11, 12, 13)]
+    with torch.no_grad():
+        encs = [m.encoder(x) for x in sets]
+        want = [_lib.check_ids(m.greedy_ids(e, START, END, 40, flags=_lib.FLAG_DECODE_GROUP8)[0].cpu()).numpy() for e in encs]
+        assert not np.array_equal(want[0], want[1])
+    pipe = GreedyPipeline(m, START, END, 40, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8, encoder_streams=2)
+    assert pipe.depth >= 3
+    order = [0, 1, 2, 2, 0, 1, 0]
+    got = []
+    for i in order:
+        if pipe.pending() >= pipe.depth:
+            got.append(pipe.collect().numpy().copy())
+        pipe.submit(sets[i])
+    while pipe.pending():
+        got.append(pipe.collect().numpy().copy())
+    assert len(got) == len(order)
+    for i, g in zip(order, got):
+        assert np.array_equal(g, want[i]), i
+
+
 def test_pipeline_falls_back_when_the_grouped_decode_times_out():
     """A batch whose grouped decode timed out (forced: silent member + 2 ms limits) is decoded again on the
     row-per-workgroup kernel inside GreedyPipeline.collect(): same ids as the healthy pipeline, one warning per batch."""
