@@ -18,7 +18,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 # the secondary configs (BASELINE configs[2..4]): bench lines with their own roofline / cpu_baseline, per-kernel stats,
 # matrix-pipe counters of the ResNet trunk
 for m in beam train resnet preprocess metrics; do
-  python bench.py --mode $m --steps 20 --warmup 3 > $OUT/bench_$m.json 2> $OUT/bench_$m.err
+  python bench.py --mode $m > $OUT/bench_$m.json 2> $OUT/bench_$m.err      # default steps / warm-up: the pipelined modes need ~25 batches to reach their steady state
 done
 for m in beam train resnet; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$m -o p -- python bench.py --mode $m --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_$m.log 2>&1
