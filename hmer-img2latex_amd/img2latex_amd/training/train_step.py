@@ -78,6 +78,7 @@ class TrainStep:
         # False keeps the whole backward on one stream (same kernels, same sums either way)
         self.side_wgrad = bool(side_wgrad)
         self._side_keep = []          # buffers the side stream's kernels still read; released after the join
+        self._ar_stream = None        # helper stream the early all-reduce piece is issued from (data parallel only)
         self._reducer = OverlappedAllReduce(self.flat_grads, self.n_early, self.group)
         L = _lib.lib()
         # zeroed once: besides scratch it carries the count of skipped (non-finite) updates across calls
@@ -120,10 +121,20 @@ class TrainStep:
 
         def after_linear():
             # decoder + FC gradients are final once the FC backward is enqueued -- and, with side-stream weight
-            # gradients, joined: their all-reduce starts there
-            if self._reducer._active():
-                self._join_side(clear=False)
-            self._reducer.start_early()
+            # gradients, once the side lanes have produced them: the early all-reduce is issued from a helper stream that
+            # waits for both, so that the conv backward on the step's own stream is not held up by the join
+            if not self._reducer._active():
+                return
+            if not self._side_keep:
+                self._reducer.start_early()
+                return
+            main = torch.cuda.current_stream()
+            if self._ar_stream is None:
+                self._ar_stream = torch.cuda.Stream(device=self.flat_grads.device)
+            self._ar_stream.wait_stream(main)
+            with torch.cuda.stream(self._ar_stream):
+                _lib.check(_lib.lib().i2l_side_stream_join(_lib.stream_ptr()), "side_stream_join")
+                self._reducer.start_early()
         encoder_train_backward(model.encoder, enc_state, denc, egr,
                                after_linear=after_linear if self.overlap_all_reduce else None, extra_flags=side,
                                keep=self._side_keep)
