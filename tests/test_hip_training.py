@@ -433,6 +433,48 @@ def test_side_stream_weight_gradients_are_the_same_numbers():
     assert torch.equal(a[ts.n:ts.n + 2], b[ts.n:ts.n + 2])      # loss sum, token count
 
 
+def test_side_wgrad_flag_through_the_c_abi():
+    """I2L_FLAG_SIDE_WGRAD + i2l_side_stream_join called the way a C host would: conv block backward (with data gradient:
+    lane 1) and linear backward (lane 0) with the flag, one join, then every output equals the one-stream call bit for bit."""
+    torch.manual_seed(9)
+    L = _lib.lib()
+    B, Cin, H, W, Cout = 8, 32, 16, 80, 64
+    x = torch.randn(B, Cin, H, W, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) / 17.0
+    b = torch.randn(Cout, device=DEV)
+    y = torch.empty(B, Cout, H // 2, W // 2, device=DEV)
+    am = torch.empty(y.shape, dtype=torch.uint8, device=DEV)
+    nb = L.i2l_conv_workspace_bytes(Cin, Cout)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    assert L.i2l_conv3x3_relu_pool2_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), am.data_ptr(), B, Cin, H, W,
+                                        Cout, ws.data_ptr(), nb, 0, _lib.stream_ptr()) == 0
+    dy = torch.randn_like(y)
+    M, K, N = 64, 2048, 256
+    fx, fw = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV) / 45.0
+    fy = torch.relu(fx @ fw.t())
+    fdy = torch.randn(M, N, device=DEV)
+    outs = []
+    for fl in (0, _lib.FLAG_SIDE_WGRAD):
+        dx, dw, db = torch.empty_like(x), torch.full_like(w, float("nan")), torch.full_like(b, float("nan"))
+        nb2 = L.i2l_conv_bwd_workspace_bytes(B, Cin, H, W, Cout)
+        ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
+        assert L.i2l_conv3x3_relu_pool2_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), am.data_ptr(), dy.data_ptr(),
+                                            dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout,
+                                            ws2.data_ptr(), nb2, fl, _lib.stream_ptr()) == 0
+        fdx, fdw, fdb = torch.empty_like(fx), torch.full_like(fw, float("nan")), torch.full((N,), float("nan"), device=DEV)
+        nb3 = L.i2l_linear_bwd_workspace_bytes(M, K, N)
+        ws3 = torch.empty(nb3, dtype=torch.uint8, device=DEV)
+        assert L.i2l_linear_bias_act_bwd(fx.data_ptr(), fw.data_ptr(), fy.data_ptr(), fdy.data_ptr(), fdx.data_ptr(),
+                                         fdw.data_ptr(), fdb.data_ptr(), M, K, N, 1, ws3.data_ptr(), nb3, fl,
+                                         _lib.stream_ptr()) == 0
+        assert L.i2l_side_stream_join(_lib.stream_ptr()) == 0          # a no-op for the one-stream call
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (dx, dw, db, fdx, fdw, fdb)])
+    for a, c in zip(outs[0], outs[1]):
+        assert not torch.isnan(c).any()
+        assert torch.equal(a, c)
+
+
 def test_data_parallel_shards_equal_full_batch():
     """SURVEY 8e parity for the DP step, emulated in one process: two ranks' flat buffers are summed
     (what the RCCL all-reduce does), then every rank applies clip + Adam with the GLOBAL count; the
