@@ -91,6 +91,11 @@ def main():
                          "CU), the conv workgroups of batch i + 1's encoder on the same CUs")
     ap.add_argument("--decode-priority", type=int, default=-1, help="pipelined region: HIP stream priority of the decode stream (-1 = high)")
     ap.add_argument("--encoder-priority", type=int, default=0, help="pipelined region: HIP stream priority of the encoder stream(s)")
+    ap.add_argument("--settle-ms", type=float, default=80.0,
+                    help="untimed run of the same step for this long BEFORE the W warm-up steps of the first timed region: after "
+                         "idle the GPU needs ~50 ms of load to reach its clocks (profiles/r03/ramp.txt: 1.5 -> 1.07 ms per batch "
+                         "over the first ~45 batches of a fresh process); 0 = none.  Reported as config.settle, the rate of the "
+                         "first K batches WITHOUT it as value_cold_start")
     ap.add_argument("--serial", action="store_true", help="time only batches back to back on one stream (the r02 default)")
     ap.add_argument("--pipelined", action="store_true",
                     help="(default since r03) time the two-stream batch pipeline (GreedyPipeline: encoder of batch i+1 beside the "
@@ -170,6 +175,21 @@ def main():
             ids, _ = model.greedy_ids(enc, synth.START, synth.END, T)
             ids_host.copy_(ids, non_blocking=True)
 
+    settled = {"batches": 0, "ms": 0.0}
+
+    def settle(step_fn, drain_fn):
+        """Untimed: the same step until --settle-ms of wall time have passed (clock ramp after idle)."""
+        if args.settle_ms <= 0:
+            return
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            for _ in range(4):
+                step_fn()
+            drain_fn()
+            torch.cuda.synchronize()
+            settled["batches"] += 4
+        settled["ms"] = round((time.perf_counter() - t_s) * 1e3, 1)
+
     def timed(step_fn, drain_fn, hooked):
         """W warmup steps, then exactly K steps between barrier + synchronize fences; returns seconds."""
         for _ in range(args.warmup):
@@ -194,7 +214,9 @@ def main():
         return dt
 
     serial_elapsed = pipelined_elapsed = None
+    cold_elapsed = None
     if args.serial:
+        settle(serial_step, lambda: None)
         elapsed = timed(serial_step, lambda: None, hooked=True)
         serial_elapsed = elapsed
     else:
@@ -213,6 +235,9 @@ def main():
             while pipe.pending():
                 last[0] = pipe.collect()
 
+        # straight after process start: W warm-up + K timed batches on clocks that are still ramping (reported, not `value`)
+        cold_elapsed = timed(pipe_step, pipe_drain, hooked=False) if args.settle_ms > 0 else None
+        settle(pipe_step, pipe_drain)
         elapsed = timed(pipe_step, pipe_drain, hooked=False)          # <- the timed region of `value`
         ids_pipe = last[0].clone()
         serial_elapsed = timed(serial_step, lambda: None, hooked=True)  # per-kernel times, undisturbed
@@ -360,7 +385,13 @@ def main():
         "roofline": roofline,
         "value_serial": round(total_tokens_per_step * args.steps / serial_elapsed, 1),
         "value_pipelined": None if pipelined_elapsed is None else round(total_tokens_per_step * args.steps / pipelined_elapsed, 1),
+        # the same W + K batches run FIRST, straight after process start, while the GPU's clocks are still ramping up from
+        # idle: what a 25 ms run measures without the settle phase (per-rank figure x ranks; not max-reduced)
+        "value_cold_start": None if cold_elapsed is None else round(total_tokens_per_step * args.steps / cold_elapsed, 1),
     }
+    result["config"]["settle"] = (f"{settled['batches']} untimed batches ({settled['ms']} ms) before the {args.warmup} warm-up steps of "
+                                  "the timed region: after idle the GPU needs ~50 ms of load to reach its clocks "
+                                  "(profiles/r03/ramp.txt); --settle-ms 0 turns it off") if settled["batches"] else "none"
 
     # ---- outside the timed region: the decode must not have timed out, and the ids must be the reference's
     _lib.check_ids(ids_host)
@@ -793,6 +824,19 @@ def extra_modes(args, world, rank, dev, dist):
                                               "dropout off, best of 2"}
         name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "backward_streams": ("1 (--no-side-wgrad)" if args.no_side_wgrad else "3: data-gradient chain on the step's stream, weight gradients on two library side streams (I2L_FLAG_SIDE_WGRAD), joined before clip + Adam"), "parallelism": f"dp{world}: one flat-buffer all-reduce" + (" (single call)" if args.dp_single_allreduce else " (issued in two pieces, the first beside the conv backward)")}
 
+    n_settle = 0
+    if args.settle_ms > 0:                      # untimed: the same step until the GPU's clocks have ramped up from idle
+        t_s = time.perf_counter()
+        # a data-parallel training step holds a collective: every rank must run the SAME number of steps (fixed count)
+        fixed = int(args.settle_ms / 2.0) if (dist is not None and args.mode == "train") else None
+        while (n_settle < fixed) if fixed is not None else ((time.perf_counter() - t_s) * 1e3 < args.settle_ms):
+            one_step()
+            n_settle += 1
+            if n_settle % 4 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        conf["settle"] = (f"{n_settle} untimed steps ({round((time.perf_counter() - t_s) * 1e3, 1)} ms) before the {args.warmup} warm-up "
+                          "steps: clock ramp after idle (profiles/r03/ramp.txt); --settle-ms 0 turns it off")
     for _ in range(args.warmup):
         one_step()
     fence()
