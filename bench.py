@@ -91,6 +91,9 @@ def main():
                          "CU), the conv workgroups of batch i + 1's encoder on the same CUs")
     ap.add_argument("--decode-priority", type=int, default=-1, help="pipelined region: HIP stream priority of the decode stream (-1 = high)")
     ap.add_argument("--encoder-priority", type=int, default=0, help="pipelined region: HIP stream priority of the encoder stream(s)")
+    ap.add_argument("--pipe-stagger-us", type=float, default=None,
+                    help="pipelined region: idle time on the encoder stream between the launch of decode(i) and encoder(i+1) "
+                         "(default: GreedyPipeline's own, 30 us in the co-resident mode; 0 = off)")
     ap.add_argument("--settle-ms", type=float, default=80.0,
                     help="untimed run of the same step for this long BEFORE the W warm-up steps of the first timed region: after "
                          "idle the GPU needs ~50 ms of load to reach its clocks (profiles/r03/ramp.txt: 1.5 -> 1.07 ms per batch "
@@ -224,7 +227,7 @@ def main():
                               rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
                               decode_flags=_lib.FLAG_DECODE_GROUP8 if args.coresident else 0,
                               decode_priority=args.decode_priority, encoder_streams=args.pipe_encoders or 1,
-                              encoder_priority=args.encoder_priority)
+                              encoder_priority=args.encoder_priority, stagger_us=args.pipe_stagger_us)
 
         def pipe_step():
             if pipe.pending() >= pipe.depth:

@@ -61,3 +61,21 @@ extern "C" int i2l_side_stream_join(i2l_stream_t stream) {
     }
     return I2L_OK;
 }
+
+// ------------------------------------------------------------------ a short device-side delay on a stream
+// GreedyPipeline holds the encoder of batch i + 1 back until the decode of batch i has been launched (an event) PLUS a few
+// tens of microseconds, so that the decode's 256 workgroups are resident before the first conv workgroup asks for a CU:
+// launched the other way round the two kernels settle into a schedule that is 15 - 20 % slower (profiles/r03/ramp.txt).
+namespace {
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = (long long)wall_clock64();      // constant 100 MHz counter
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+extern "C" int i2l_stream_spin_us(float microseconds, i2l_stream_t stream) {
+    if (!(microseconds >= 0.f) || microseconds > 10000.f) return I2L_ERR_ARG;      // bounded: at most 10 ms
+    if (microseconds == 0.f) return I2L_OK;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, i2l_s(stream), (long long)(microseconds * 100.f));
+    return hipGetLastError() == hipSuccess ? I2L_OK : I2L_ERR_LAUNCH;
+}

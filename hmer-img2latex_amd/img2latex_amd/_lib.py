@@ -51,6 +51,7 @@ _SIGNATURES = {
     "i2l_version": (c_int, []),
     "i2l_error_string": (c_char_p, [c_int]),
     "i2l_side_stream_join": (c_int, [c_void_p]),
+    "i2l_stream_spin_us": (c_int, [ctypes.c_float, c_void_p]),
     "i2l_conv_workspace_bytes": (c_size_t, [c_int, c_int]),
     "i2l_conv3x3_relu_pool2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
@@ -202,9 +203,11 @@ def pointer_array(tensors: Sequence[torch.Tensor]):
 _STAGE_HOOK = None
 
 
-def set_stage_hook(fn) -> None:
+def set_stage_hook(fn):
+    """Installs ``fn(name)`` (or None) as the stage hook and returns the one it replaces."""
     global _STAGE_HOOK
-    _STAGE_HOOK = fn
+    old, _STAGE_HOOK = _STAGE_HOOK, fn
+    return old
 
 
 def mark(name: str) -> None:

@@ -28,7 +28,7 @@ class GreedyPipeline:
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
                  decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1,
-                 encoder_priority: int = 0):
+                 encoder_priority: int = 0, stagger_us: Optional[float] = None):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -50,6 +50,16 @@ class GreedyPipeline:
         # batch's encoder on the same CU: the two kernels share the chip by resource, not by CU count
         self.decode_flags = int(decode_flags)
         self.encoder_flags = int(encoder_flags)          # e.g. _lib.FLAG_CONV_ONE_PER_CU while the pipeline runs
+        # Co-resident mode with one encoder stream: the encoder of batch i + 1 is held back until the decode of batch i has been
+        # LAUNCHED (event recorded after its prepare) plus `stagger_us` of idling on the encoder stream, so that the decode's
+        # 256 workgroups are resident before the first conv workgroup asks for a CU.  Launched the other way round -- conv0 of
+        # batch i + 1 beside prepare(i), conv1 racing the decode for CUs -- the two kernels fall into a schedule in which conv1
+        # crawls for the whole decode and conv2 / FC follow alone: 1.25 - 1.45 ms per batch instead of 1.07.  Left alone the
+        # pipeline drifts out of that schedule within 5 - 45 batches (profiles/r03/ramp.txt); with the stagger it never enters it.
+        if stagger_us is None:
+            stagger_us = 30.0 if (self.decode_flags & _lib.FLAG_DECODE_GROUP8) and len(self.enc_streams) == 1 else 0.0
+        self.stagger_us = float(stagger_us)
+        self._launch_ev = None
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor, torch.Tensor]] = deque()
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
         self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
@@ -64,6 +74,9 @@ class GreedyPipeline:
         enc_stream.wait_stream(cur)                           # images were produced on the caller's stream
         with torch.no_grad():
             with torch.cuda.stream(enc_stream):
+                if self.stagger_us > 0 and self._launch_ev is not None:
+                    enc_stream.wait_event(self._launch_ev)
+                    _lib.check(_lib.lib().i2l_stream_spin_us(self.stagger_us, _lib.stream_ptr()), "stream_spin_us")
                 saved = self.model.encoder.kernel_flags
                 self.model.encoder.kernel_flags = saved | self.encoder_flags
                 try:
@@ -78,8 +91,22 @@ class GreedyPipeline:
             with torch.cuda.stream(dec_stream):
                 dec_stream.wait_event(enc_done)
                 enc.record_stream(dec_stream)
-                ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
-                                               rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags)
+                old_hook = None
+                if self.stagger_us > 0:
+                    def _hook(name, _s=dec_stream):
+                        if name == "prepare":                      # enqueued: the decode kernel is the next launch on _s
+                            ev = torch.cuda.Event()
+                            ev.record(_s)
+                            self._launch_ev = ev
+                        if old_hook is not None:
+                            old_hook(name)
+                    old_hook = _lib.set_stage_hook(_hook)
+                try:
+                    ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
+                                                   rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags)
+                finally:
+                    if self.stagger_us > 0:
+                        _lib.set_stage_hook(old_hook)
                 host = self._host_buffer(ids.shape)
                 host.copy_(ids, non_blocking=True)
                 done = torch.cuda.Event()

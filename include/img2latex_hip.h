@@ -83,6 +83,10 @@ const char* i2l_error_string(int code);
  * `loss.backward()` (trainer.py:337) before `optimizer.step()` (trainer.py:343) by itself; here the caller of the
  * backward entry points states that order once per step. */
 int i2l_side_stream_join(i2l_stream_t stream);
+/* Enqueues a one-wave kernel that idles for `microseconds` (<= 10000) on `stream`: GreedyPipeline's stagger between the launch
+ * of decode(i) and the first kernel of encoder(i + 1) (no counterpart in the reference, which runs one batch at a time,
+ * predictor.py:205-381). */
+int i2l_stream_spin_us(float microseconds, i2l_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Encoder (reference img2latex/model/encoder.py)
