@@ -892,7 +892,7 @@ def extra_modes(args, world, rank, dev, dist):
         # providing the encoder's time for the roofline and is a floor for `value`
         n_enc = args.pipe_encoders or 2
         pipe = GreedyPipeline(model, synth.START, synth.END, T, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8,
-                              decode_priority=args.decode_priority, encoder_streams=n_enc)
+                              decode_priority=args.decode_priority, encoder_streams=n_enc, stagger_us=args.pipe_stagger_us)
 
         piped_ids = [None]
 

@@ -56,10 +56,12 @@ class GreedyPipeline:
         # batch i + 1 beside prepare(i), conv1 racing the decode for CUs -- the two kernels fall into a schedule in which conv1
         # crawls for the whole decode and conv2 / FC follow alone: 1.25 - 1.45 ms per batch instead of 1.07.  Left alone the
         # pipeline drifts out of that schedule within 5 - 45 batches (profiles/r03/ramp.txt); with the stagger it never enters it.
+        # With n encoder streams the encoder of batch j waits for the launch of decode(j - n): every encoder starts at a decode
+        # launch, n of them in flight.
         if stagger_us is None:
-            stagger_us = 30.0 if (self.decode_flags & _lib.FLAG_DECODE_GROUP8) and len(self.enc_streams) == 1 else 0.0
+            stagger_us = 30.0 if (self.decode_flags & _lib.FLAG_DECODE_GROUP8) else 0.0
         self.stagger_us = float(stagger_us)
-        self._launch_ev = None
+        self._launch_evs: Deque[torch.cuda.Event] = deque(maxlen=len(self.enc_streams))
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor, torch.Tensor]] = deque()
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
         self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
@@ -74,8 +76,8 @@ class GreedyPipeline:
         enc_stream.wait_stream(cur)                           # images were produced on the caller's stream
         with torch.no_grad():
             with torch.cuda.stream(enc_stream):
-                if self.stagger_us > 0 and self._launch_ev is not None:
-                    enc_stream.wait_event(self._launch_ev)
+                if self.stagger_us > 0 and len(self._launch_evs) == self._launch_evs.maxlen:
+                    enc_stream.wait_event(self._launch_evs[0])     # launch of decode(j - n)
                     _lib.check(_lib.lib().i2l_stream_spin_us(self.stagger_us, _lib.stream_ptr()), "stream_spin_us")
                 saved = self.model.encoder.kernel_flags
                 self.model.encoder.kernel_flags = saved | self.encoder_flags
@@ -97,7 +99,7 @@ class GreedyPipeline:
                         if name == "prepare":                      # enqueued: the decode kernel is the next launch on _s
                             ev = torch.cuda.Event()
                             ev.record(_s)
-                            self._launch_ev = ev
+                            self._launch_evs.append(ev)
                         if old_hook is not None:
                             old_hook(name)
                     old_hook = _lib.set_stage_hook(_hook)
