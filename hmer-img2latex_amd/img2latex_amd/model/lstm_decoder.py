@@ -104,8 +104,11 @@ class LSTMDecoder(nn.Module):
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def prepare(self, encoder_output: torch.Tensor, reuse_weight_images: bool = True):
+    def prepare(self, encoder_output: torch.Tensor, reuse_weight_images: bool = True, slot=None):
         """Build the decode workspace for these encoder rows (i2l_decoder_prepare).
+        ``slot`` (any hashable): use the workspace of that name instead of the current stream's -- a pipeline prepares batch
+        i + 1 on its encoder stream while decode(i) still reads the workspace of batch i, then passes what this returns
+        (plus ``self._ws``) to ``run_steps(prepared=...)``.
         The weight images (transposed / gate-interleaved matrices, the token table P) are rebuilt only
         when a parameter changed since they were built -- (data_ptr, _version) of every parameter is
         the cache key, the same contract as nn.LSTM's flattened weights; code that writes parameters
@@ -123,7 +126,7 @@ class LSTMDecoder(nn.Module):
             raise RuntimeError("img2latex_amd: decoder dimensions not supported by the HIP kernels")
         key = (rows, enc.device, self._weights_version())
         what = _lib.PREP_ALL
-        sid = _lib.stream_ptr()
+        sid = _lib.stream_ptr() if slot is None else ("slot", slot)
         self._ws, self._ws_key = self._ws_by_stream.get(sid, (None, None))
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != enc.device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
@@ -155,9 +158,15 @@ class LSTMDecoder(nn.Module):
                   temperature: float = 1.0, select: int = _lib.SELECT_LOGITS, stop: int = _lib.STOP_NONE,
                   end_id: int = -1, want_ids: bool = True, want_logits: bool = False,
                   want_state: bool = False, reuse_weight_images: bool = True, rows_per_workgroup: int = 0,
-                  flags: int = 0):
-        """prepare + one persistent i2l_greedy_decode launch.  Returns (ids, logits, (h, c))."""
-        w, keep, enc = self.prepare(encoder_output, reuse_weight_images)
+                  flags: int = 0, prepared=None):
+        """prepare + one persistent i2l_greedy_decode launch.  Returns (ids, logits, (h, c)).
+        ``prepared`` = (w, keep, enc, workspace) of an earlier ``prepare(encoder_output, slot=...)`` whose completion the
+        current stream already waits for: the launch uses that workspace and prepares nothing."""
+        if prepared is None:
+            w, keep, enc = self.prepare(encoder_output, reuse_weight_images)
+            ws = self._ws
+        else:
+            w, keep, enc, ws = prepared
         rows, dev = enc.shape[0], enc.device
         tok0 = _lib.require_gpu(tok0, "tok0", torch.int32)
         if forced is not None:
@@ -178,7 +187,7 @@ class LSTMDecoder(nn.Module):
             h = torch.empty((self.lstm_layers, rows, self.hidden_dim), dtype=torch.float32, device=dev)
             c = torch.empty_like(h)
         _lib.check(_lib.lib().i2l_greedy_decode_ex(
-            ctypes.byref(w), self._ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(forced), _lib.ptr(h0),
+            ctypes.byref(w), ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(forced), _lib.ptr(h0),
             _lib.ptr(c0), float(temperature), select, stop, int(end_id), int(rows_per_workgroup), _lib.ptr(ids),
             _lib.ptr(logits), _lib.ptr(h), _lib.ptr(c), int(flags) | int(self.kernel_flags), _lib.stream_ptr()),
             "greedy_decode")

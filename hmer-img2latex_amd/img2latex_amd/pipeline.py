@@ -63,11 +63,13 @@ class GreedyPipeline:
         self.stagger_us = float(stagger_us)
         self._launch_evs: Deque[torch.cuda.Event] = deque(maxlen=len(self.enc_streams))
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor, torch.Tensor]] = deque()
+        self._batch_no = 0
+        self._slots = self.depth + 1                 # decoder workspaces in rotation: a slot is rewritten only after its batch was collected
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
         self._lent: Optional[torch.Tensor] = None    # buffer handed to the caller by the last collect()
 
     def submit(self, images: torch.Tensor) -> None:
-        """Enqueue encoder (stream A) and prepare + decode + id copy (stream B) for one batch."""
+        """Enqueue encoder + decoder prepare (stream A) and decode + id copy (stream B) for one batch."""
         if len(self._inflight) >= self.depth:
             raise RuntimeError(f"GreedyPipeline: {self.depth} batches already in flight; collect() first")
         cur = torch.cuda.current_stream(self.device)
@@ -85,6 +87,13 @@ class GreedyPipeline:
                     enc = self.model.encoder(images)
                 finally:
                     self.model.encoder.kernel_flags = saved
+                # the decoder's per-batch tables (i2l_decoder_prepare) are built here, on the ENCODER stream right behind the FC
+                # layer, into one of `depth + 1` workspaces: the decode stream then goes from decode(i) straight into
+                # decode(i + 1) (the two small prepare launches used to sit between them, ~50 us per batch)
+                slot = self._batch_no % self._slots
+                self._batch_no += 1
+                w, keep, enc_c = self.model.decoder.prepare(enc, slot=("pipe", id(self), slot))
+                prepared = (w, keep, enc_c, self.model.decoder._ws)
                 enc_done = torch.cuda.Event()
                 enc_done.record(enc_stream)
             images.record_stream(enc_stream)
@@ -93,22 +102,13 @@ class GreedyPipeline:
             with torch.cuda.stream(dec_stream):
                 dec_stream.wait_event(enc_done)
                 enc.record_stream(dec_stream)
-                old_hook = None
-                if self.stagger_us > 0:
-                    def _hook(name, _s=dec_stream):
-                        if name == "prepare":                      # enqueued: the decode kernel is the next launch on _s
-                            ev = torch.cuda.Event()
-                            ev.record(_s)
-                            self._launch_evs.append(ev)
-                        if old_hook is not None:
-                            old_hook(name)
-                    old_hook = _lib.set_stage_hook(_hook)
-                try:
-                    ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
-                                                   rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags)
-                finally:
-                    if self.stagger_us > 0:
-                        _lib.set_stage_hook(old_hook)
+                if self.stagger_us > 0:                            # the decode kernel is the next launch on this stream
+                    ev = torch.cuda.Event()
+                    ev.record(dec_stream)
+                    self._launch_evs.append(ev)
+                ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
+                                               rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags,
+                                               prepared=prepared)
                 host = self._host_buffer(ids.shape)
                 host.copy_(ids, non_blocking=True)
                 done = torch.cuda.Event()
