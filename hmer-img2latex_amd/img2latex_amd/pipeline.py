@@ -28,7 +28,8 @@ class GreedyPipeline:
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
                  decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1,
-                 encoder_priority: int = 0, stagger_us: Optional[float] = None):
+                 encoder_priority: int = 0, stagger_us: Optional[float] = None, stop: int = _lib.STOP_NONE,
+                 select: int = _lib.SELECT_LOGITS):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -49,6 +50,7 @@ class GreedyPipeline:
         # instead -- one wave per SIMD and 80 KB of LDS on EVERY CU, which leaves room for one conv workgroup of the next
         # batch's encoder on the same CU: the two kernels share the chip by resource, not by CU count
         self.decode_flags = int(decode_flags)
+        self.stop, self.select = int(stop), int(select)   # STOP_STICKY + SELECT_SOFTMAX = Predictor.predict_batch's loop
         self.encoder_flags = int(encoder_flags)          # e.g. _lib.FLAG_CONV_ONE_PER_CU while the pipeline runs
         # Co-resident mode with one encoder stream: the encoder of batch i + 1 is held back until the decode of batch i has been
         # LAUNCHED (event recorded after its prepare) plus `stagger_us` of idling on the encoder stream, so that the decode's
@@ -107,6 +109,7 @@ class GreedyPipeline:
                     ev.record(dec_stream)
                     self._launch_evs.append(ev)
                 ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
+                                               stop=self.stop, select=self.select,
                                                rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags,
                                                prepared=prepared)
                 host = self._host_buffer(ids.shape)
@@ -139,7 +142,7 @@ class GreedyPipeline:
                           "row-per-workgroup kernel", RuntimeWarning)
             with torch.no_grad():
                 ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
-                                               rows_per_workgroup=1)
+                                               stop=self.stop, select=self.select, rows_per_workgroup=1)
             host.copy_(ids)
         if self._lent is not None:
             self._free.append(self._lent)

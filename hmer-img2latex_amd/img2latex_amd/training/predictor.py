@@ -194,6 +194,31 @@ class Predictor:
         lens = np.where(stop.any(axis=1), stop.argmax(axis=1), a.shape[1]).tolist()
         return [[start] + row[:n] for row, n in zip(a.tolist(), lens)]
 
+    def predict_ids_stream(self, batches, max_length: int = 141, temperature: float = 1.0):
+        """``predict_batch_ids`` (the greedy branch: argmax of softmax, sticky stop) for a STREAM of image batches, through
+        ``GreedyPipeline``: the decode of batch i shares the GPU with the encoder of batch i + 1 (two batches in flight, the
+        schedule bench.py times).  Yields one ``List[List[int]]`` per batch, in order, equal to what ``predict_batch_ids``
+        returns for that batch (up to fp32 near-ties between the two decode kernels)."""
+        from ..pipeline import GreedyPipeline
+        start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
+        n_enc = 2 if hasattr(self.model.encoder, "_trunk_train") else 1      # ResNet trunk: two in flight
+        pipe = GreedyPipeline(self.model, start, end, max_length, temperature, rows_per_workgroup=0,
+                              decode_flags=_lib.FLAG_DECODE_GROUP8, decode_priority=-1, encoder_streams=n_enc,
+                              stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX)
+
+        def finish(ids_host):
+            a = ids_host.numpy()
+            stop = (a == end) | (a < 0)
+            lens = np.where(stop.any(axis=1), stop.argmax(axis=1), a.shape[1]).tolist()
+            return [[start] + row[:n] for row, n in zip(a.tolist(), lens)]
+
+        for images in batches:
+            if pipe.pending() >= pipe.depth:
+                yield finish(pipe.collect())
+            pipe.submit(self._as_batch(images))
+        while pipe.pending():
+            yield finish(pipe.collect())
+
     def evaluate_batch(self, images, targets: torch.Tensor, max_length: Optional[int] = None) -> Dict:
         """One batch of the reference's ``evaluate`` command (cli.py:449-495) with every stage on the device and
         the token ids never leaving HBM between them:

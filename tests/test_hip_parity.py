@@ -610,6 +610,27 @@ def test_resnet_encoder_vs_oracle(model_name, hw):
     enc.eval()
 
 
+def test_predict_ids_stream_equals_predict_batch_ids():
+    """Predictor.predict_ids_stream (GreedyPipeline with the Predictor's loop: argmax of softmax, sticky stop): batch by batch
+    the lists predict_batch_ids returns -- on a tiny attention model (no grouped kernels: the pipeline's C call picks the
+    row-per-workgroup kernel) and at the primary dims (8-member co-resident decode; a row may leave the 4-member kernel's
+    ids only at an fp32 near-tie, judged by the reference fixture's margins); ragged last batch, order preserved."""
+    from img2latex_amd.training import Predictor, TokenTable
+    for name, n_imgs, bs, T in (("tiny_l2_attn", 10, 4, 24), ("primary_cfg2_clock", 160, 64, 60)):
+        d, cfg, sd_kw = load(name)
+        m, _ = model_for(name, sd_kw, cfg) if name != "tiny_l2_attn" else model_for(name)
+        vocab = {"<PAD>": 0, "<START>": 1, "<END>": 2, "<UNK>": 3}
+        vocab.update({f"t{i}": i for i in range(4, cfg["vocab_size"])})
+        pred = Predictor(m, TokenTable(vocab, max_sequence_length=150), device=torch.device(DEV))
+        x = torch.from_numpy(synth.make_images(n_imgs, cfg, seed=1234)).to(DEV)
+        batches = [x[i:i + bs] for i in range(0, n_imgs, bs)]
+        want = [pred.predict_batch_ids(b, max_length=T) for b in batches]
+        got = list(pred.predict_ids_stream(iter(batches), max_length=T))
+        assert [len(g) for g in got] == [len(w) for w in want]
+        differ = sum(1 for g, w in zip(got, want) for a, b in zip(g, w) if a != b)
+        assert differ <= (0 if name == "tiny_l2_attn" else 2), (name, differ)
+
+
 def test_predictor_and_checkpoint_roundtrip(tmp_path):
     """Checkpoint dict of trainer.py:209-224 -> Predictor.from_checkpoint (predictor.py:61-137) -> strings."""
     from img2latex_amd.training import Predictor, TokenTable, TrainStep, save_checkpoint
