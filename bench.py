@@ -20,6 +20,10 @@ share the chip by resource).  Every batch still runs the full encoder, prepare, 
 all K batches complete inside the timed region.  A second, SERIAL pass of K batches (one stream, each kernel alone on
 the chip, the 4-member grouped decode) follows: it provides the per-kernel times of the roofline object, `value_serial`,
 and a floor -- `value` is never worse than it.  --serial times only that pass (the r02 default).
+Order of a default run: [W warm-up + K timed batches straight after start-up -> `value_cold_start`], [--settle-ms of the same
+step, untimed: the GPU's clocks need ~50 ms of load after idle, profiles/r03/ramp.txt -> `config.settle`], [W warm-up +
+EXACTLY K timed batches between barrier + synchronize fences -> `value`], [the serial pass], then the parity checks of both
+regions' ids against the reference fixture.
 
 Prints ONE JSON line (rank 0) with the driver's keys plus "roofline" (dominant kernel,
 timed live with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on
