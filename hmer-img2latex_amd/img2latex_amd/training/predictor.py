@@ -238,10 +238,13 @@ class Predictor:
         """``evaluate_batch`` over an iterable of (images, targets), one result per batch in order, software-pipelined:
         the host work of batch i+1 (shape pass, packing the ragged pages into pinned memory, their upload on a side
         stream) runs while the device is still busy with batch i, and the host only waits for batch i's statistics
-        after batch i+1 has been enqueued.  This is the loop of cli.py:449-495."""
+        after batch i+1 has been enqueued.  On the device the two batches in flight share the GPU the way GreedyPipeline's
+        do: preprocessing + encoder + decoder prepare of batch i+1 on one stream, the decode (8-member grouped kernel) +
+        id compaction + statistics of batch i on another, the first held back until the second's decode has been launched.
+        This is the loop of cli.py:449-495."""
         pending = None
         for images, targets in batches:
-            handle = self._evaluate_launch(images, targets, max_length, side_upload=True)
+            handle = self._evaluate_launch(images, targets, max_length, side_upload=True, coresident=True)
             if pending is not None:
                 yield self._evaluate_finish(pending)
             pending = handle
@@ -249,49 +252,87 @@ class Predictor:
             yield self._evaluate_finish(pending)
 
     def _evaluate_launch(self, images, targets: torch.Tensor, max_length: Optional[int], side_upload: bool = False,
-                         rows_per_workgroup: int = 0):
-        """Enqueues the whole chain of one batch and the copy of its statistics to pinned memory; no host wait."""
+                         rows_per_workgroup: int = 0, coresident: bool = False):
+        """Enqueues the whole chain of one batch and the copy of its statistics to pinned memory; no host wait.
+        ``coresident``: two streams -- everything up to the decoder's prepare on the first, the decode and what follows on the
+        second (see evaluate_stream); otherwise the whole chain on the current stream."""
         from . import metrics as M
+        import contextlib
         L = _lib.lib()
         tk = self.tokenizer
         raw = images
-        if not isinstance(images, torch.Tensor):
-            from ..data import preprocess_batch
-            enc_mod = self.model.encoder
-            if side_upload and getattr(self, "_up_stream", None) is None:
-                self._up_stream = torch.cuda.Stream(self.device)
-            with torch.cuda.device(self.device):
-                images = preprocess_batch(list(images), (enc_mod.img_height, enc_mod.img_width), enc_mod.channels, True,
-                                          upload_stream=self._up_stream if side_upload else None)
-        x = self._as_batch(images)
-        B = x.shape[0]
+        # host-side preparation and everything that touches the CALLER's stream first (targets, the small constant tensors)
         T = int(max_length if max_length is not None else tk.max_sequence_length)
         tgt = targets.to(self.device, dtype=torch.int32).contiguous()
-        if tgt.dim() != 2 or tgt.shape[0] != B:
-            raise RuntimeError(f"targets must be ({B}, L) token ids, got {tuple(tgt.shape)}")
+        if tgt.dim() != 2:
+            raise RuntimeError(f"targets must be (B, L) token ids, got {tuple(tgt.shape)}")
         special = getattr(tk, "special_tokens", DEFAULT_SPECIAL_TOKENS)
         drop = sorted({tk.token_to_id[t] for t in special.values()}) if hasattr(tk, "token_to_id") else \
             sorted({tk.pad_token_id, tk.start_token_id, tk.end_token_id})
         if len(drop) > 8:
             raise NotImplementedError("img2latex_amd: at most 8 special token ids")
-        dev = x.device
+        dev = tgt.device
         key = (tuple(drop), tk.pad_token_id, dev)
         if getattr(self, "_drop_key", None) != key:
             self._drop = torch.tensor(drop, dtype=torch.int32, device=dev)
             self._pad = torch.tensor([tk.pad_token_id], dtype=torch.int32, device=dev)
             self._drop_key = key
+        cur = torch.cuda.current_stream(self.device)
+        if coresident:
+            st = self.__dict__.setdefault("_ev_streams", {})
+            if "enc" not in st:
+                st["enc"] = torch.cuda.Stream(self.device)
+                st["dec"] = torch.cuda.Stream(self.device, priority=-1)
+                st["launched"], st["n"] = None, 0
+            s_enc, s_dec = st["enc"], st["dec"]
+            s_enc.wait_stream(cur)                           # the caller's tensors, tgt, the constants
+            on_enc = lambda: torch.cuda.stream(s_enc)
+            on_dec = lambda: torch.cuda.stream(s_dec)
+        else:
+            on_enc = on_dec = contextlib.nullcontext
+        with on_enc():
+            if coresident and st["launched"] is not None:    # not before the previous batch's decode has been launched
+                s_enc.wait_event(st["launched"])
+                _lib.check(L.i2l_stream_spin_us(30.0, _lib.stream_ptr()), "stream_spin_us")
+            if not isinstance(images, torch.Tensor):
+                from ..data import preprocess_batch
+                enc_mod = self.model.encoder
+                if side_upload and getattr(self, "_up_stream", None) is None:
+                    self._up_stream = torch.cuda.Stream(self.device)
+                with torch.cuda.device(self.device):
+                    images = preprocess_batch(list(images), (enc_mod.img_height, enc_mod.img_width), enc_mod.channels, True,
+                                              upload_stream=self._up_stream if side_upload else None)
+            x = self._as_batch(images)
+        B = x.shape[0]
+        if tgt.shape[0] != B:
+            raise RuntimeError(f"targets must be ({B}, L) token ids, got {tuple(tgt.shape)}")
         W = max(T, tgt.shape[1])
-        p_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
-        t_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
-        p_len = torch.empty((B,), dtype=torch.int32, device=dev)
-        t_len = torch.empty((B,), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        prepared = None
+        with on_enc(), torch.cuda.device(dev), torch.no_grad():
+            t_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
+            t_len = torch.empty((B,), dtype=torch.int32, device=dev)
             _lib.check(L.i2l_compact_ids(tgt.data_ptr(), B, tgt.shape[1], tgt.stride(0), -1, self._pad.data_ptr(), 1,
                                          t_ids.data_ptr(), W, t_len.data_ptr(), _lib.stream_ptr()), "compact_ids")
+            enc = self.model.encoder(x)
+            if coresident:
+                w_, keep_, enc_c = self.model.decoder.prepare(enc, slot=("eval", id(self), st["n"] % 3))
+                st["n"] += 1
+                prepared = (w_, keep_, enc_c, self.model.decoder._ws)
+                enc_done = torch.cuda.Event()
+                enc_done.record(s_enc)
+        with on_dec(), torch.cuda.device(dev):
+            if coresident:
+                s_dec.wait_event(enc_done)
+                for t_ in (x, tgt, t_ids, t_len, enc):
+                    t_.record_stream(s_dec)                  # allocated on the first stream, read on the second
+                st["launched"] = torch.cuda.Event()
+                st["launched"].record(s_dec)                 # the decode kernel is the next launch on this stream
+            p_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
+            p_len = torch.empty((B,), dtype=torch.int32, device=dev)
             with torch.no_grad():
-                enc = self.model.encoder(x)
                 ids, _ = self.model.greedy_ids(enc, tk.start_token_id, tk.end_token_id, T, stop=_lib.STOP_STICKY,
-                                               select=_lib.SELECT_SOFTMAX, rows_per_workgroup=rows_per_workgroup)
+                                               select=_lib.SELECT_SOFTMAX, rows_per_workgroup=rows_per_workgroup,
+                                               flags=_lib.FLAG_DECODE_GROUP8 if coresident else 0, prepared=prepared)
                 _lib.check(L.i2l_compact_ids(ids.data_ptr(), B, T, ids.stride(0), int(tk.end_token_id),
                                              self._drop.data_ptr(), len(drop), p_ids.data_ptr(), W, p_len.data_ptr(),
                                              _lib.stream_ptr()), "compact_ids")
