@@ -528,7 +528,7 @@ def beside_paths(model, cfg, images, B, T, reps):
                              "ms_per_batch_pipelined": round(dt_stream * 1e3, 3),
                              "ms_per_batch_from_device_tensors": round(ev[0].elapsed_time(ev[1]) / reps, 3),
                              "bleu": res["bleu"], "levenshtein": res["levenshtein"],
-                             "pipelined": "Predictor.evaluate_stream: host packing + upload (side stream) of batch i+1 beside the kernels of batch i",
+                             "pipelined": "Predictor.evaluate_stream: host packing + upload (side stream) of batch i+1 beside the kernels of batch i; on the device decode(i) beside preprocessing + encoder(i+1) (two streams, as GreedyPipeline); from ragged host pages the host is the bound, ms_per_batch_stream_from_device_tensors shows the device side alone",
                              "includes": "host resize plans + upload of ragged uint8 pages, preprocess, encoder, decode "
                                          f"({T} steps, sticky stop), id compaction, sequence statistics, float64 scores"}
     return out
