@@ -65,6 +65,7 @@ class GreedyPipeline:
         self.stagger_us = float(stagger_us)
         self._launch_evs: Deque[torch.cuda.Event] = deque(maxlen=len(self.enc_streams))
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor, torch.Tensor]] = deque()
+        self.copy_stream = torch.cuda.Stream(device=dev)     # the ids' device -> host copies (off the decode stream: +1 %)
         self._batch_no = 0
         self._slots = self.depth + 1                 # decoder workspaces in rotation: a slot is rewritten only after its batch was collected
         self._free: List[torch.Tensor] = []          # pinned host buffers not in use
@@ -113,9 +114,19 @@ class GreedyPipeline:
                                                rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags,
                                                prepared=prepared)
                 host = self._host_buffer(ids.shape)
-                host.copy_(ids, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(dec_stream)
+                if self.copy_stream is None:
+                    host.copy_(ids, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(dec_stream)
+                else:                                              # the id copy leaves the decode stream: decode(i + 1) need not wait for it
+                    decoded = torch.cuda.Event()
+                    decoded.record(dec_stream)
+                    self.copy_stream.wait_event(decoded)
+                    with torch.cuda.stream(self.copy_stream):
+                        host.copy_(ids, non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record(self.copy_stream)
+                    ids.record_stream(self.copy_stream)
         self._inflight.append((done, host, enc))
 
     def _host_buffer(self, shape) -> torch.Tensor:
