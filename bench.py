@@ -95,9 +95,10 @@ def main():
                          "CU), the conv workgroups of batch i + 1's encoder on the same CUs")
     ap.add_argument("--decode-priority", type=int, default=-1, help="pipelined region: HIP stream priority of the decode stream (-1 = high)")
     ap.add_argument("--encoder-priority", type=int, default=0, help="pipelined region: HIP stream priority of the encoder stream(s)")
-    ap.add_argument("--pipe-stagger-us", type=float, default=None,
-                    help="pipelined region: idle time on the encoder stream between the launch of decode(i) and encoder(i+1) "
-                         "(default: GreedyPipeline's own, 30 us in the co-resident mode; 0 = off)")
+    ap.add_argument("--pipe-no-hold", action="store_true",
+                    help="pipelined region, A/B: do NOT hold encoder(i+1) back until decode(i) is resident (the dependency "
+                         "GreedyPipeline adds in the co-resident mode: i2l_greedy_decode_ex's residency signal + "
+                         "i2l_stream_wait_value32 on the encoder stream)")
     ap.add_argument("--settle-ms", type=float, default=80.0,
                     help="untimed run of the same step for this long BEFORE the W warm-up steps of the first timed region: after "
                          "idle the GPU needs ~50 ms of load to reach its clocks (profiles/r03/ramp.txt: 1.5 -> 1.07 ms per batch "
@@ -112,7 +113,7 @@ def main():
                     help="--mode train: ONE all-reduce of the flat gradient buffer after the backward pass instead of the "
                          "default two pieces (same sums), the first of which overlaps the conv backward")
     ap.add_argument("--no-side-wgrad", action="store_true",
-                    help="--mode train: keep the weight-gradient kernels on the step's own stream (default: library side stream)")
+                    help="--mode train: keep the weight-gradient kernels on the step's own stream (default: two side lanes owned by TrainStep)")
     ap.add_argument("--launch-probe", action="store_true",
                     help="rendezvous check only (CPU, gloo): every rank all-reduces its rank number, rank 0 prints "
                          "{n_gpus, ranks_seen}; exercises the self-launch path of `--gpus N` without a GPU")
@@ -124,7 +125,7 @@ def main():
         os.environ.setdefault("I2L_DIST_BACKEND", "gloo")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU
-        # yet (device_count() does not initialise it), and the ranks are CHILD processes, never an exec of this one
+        # (GPUs are counted from sysfs), and the ranks are CHILD processes, never an exec of this one
         raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -231,7 +232,7 @@ def main():
                               rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
                               decode_flags=_lib.FLAG_DECODE_GROUP8 if args.coresident else 0,
                               decode_priority=args.decode_priority, encoder_streams=args.pipe_encoders or 1,
-                              encoder_priority=args.encoder_priority, stagger_us=args.pipe_stagger_us)
+                              encoder_priority=args.encoder_priority, hold_encoder=False if args.pipe_no_hold else None)
 
         def pipe_step():
             if pipe.pending() >= pipe.depth:
@@ -245,7 +246,11 @@ def main():
         # straight after process start: W warm-up + K timed batches on clocks that are still ramping (reported, not `value`)
         cold_elapsed = timed(pipe_step, pipe_drain, hooked=False) if args.settle_ms > 0 else None
         settle(pipe_step, pipe_drain)
+        # HIP events of the timed region, on the streams the kernels are launched on: the warm-up batches are traced too and
+        # dropped below (exactly the last K records are the timed batches)
+        pipe.trace = []
         elapsed = timed(pipe_step, pipe_drain, hooked=False)          # <- the timed region of `value`
+        pipe_trace, pipe.trace = pipe.trace[-args.steps:], None
         ids_pipe = last[0].clone()
         serial_elapsed = timed(serial_step, lambda: None, hooked=True)  # per-kernel times, undisturbed
         last[0] = ids_host
@@ -300,37 +305,94 @@ def main():
     # HBM bytes per launch of the dominant kernel: hardware counters cannot be read inside this run (rocprofv3 --pmc
     # is its own pass and serialises the kernels), so `traffic` is the figure of the LATEST committed counter collection
     # of this same command (profiles/collect.sh -> profiles/traffic.json), and `traffic_from` says which one
-    traffic = traffic_from = None
+    tj, traffic_from = {}, None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        traffic = tj.get(dom["kernel"])
         traffic_from = tj.get("_collection", "profiles/traffic.json (rocprofv3 --pmc passes of `python bench.py`, collection "
                                              "not recorded)") + " -- a separate counter pass, not this timed run"
-    # What bounds the dominant kernel.  The decode loop's matrix work (1.835 MFLOP/token algorithmic) is
-    # priced against the fp32 peak as the contract asks, but the kernel is NOT arithmetic-bound: it runs on the vector
-    # ALUs (v_pk_fma_f32, no MFMA), executes only 0.786 MFLOP/token (the W_ih [emb | enc] half of the gate GEMM is
-    # hoisted into the P / Genc tables by `prepare`), and every one of its 150 steps waits on two exchanges between the
-    # four workgroups of a group through L2: a latency chain.  The conv blocks / FC run on the bf16 matrix cores (3-way
-    # split operands, 6 bf16 products per fp32 product).
-    roofline = dict(kernel=dom["kernel"], achieved=dom["tflops"], peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
-                    frac=round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), traffic=traffic, traffic_from=traffic_from,
-                    launch_ms=dom["ms"])
+    H_, V_, L_ = cfg["hidden_dim"], cfg["vocab_size"], cfg["lstm_layers"]
+    run_flops = 2.0 * (4 * H_ * H_ * (2 * L_ - 1) + H_ * V_) * B * executed_steps_holder[0]
+
+    def decode_view(kernel, ms, members):
+        """Roofline entry of a grouped decode kernel.  The loop's matrix work (1.835 MFLOP/token algorithmic) is
+        priced against the fp32 peak as the contract asks, but the kernel is NOT arithmetic-bound: it runs on the vector ALUs
+        (v_pk_fma_f32, no MFMA), executes only 0.786 MFLOP/token (the W_ih [emb | enc] half of the gate GEMM is hoisted into
+        the P / Genc tables by `prepare`), and every one of its steps waits on two exchanges between the workgroups of a
+        group through L2: a latency chain."""
+        tf = costs["decode"]["flops"] / ms / 1e9
+        return dict(kernel=kernel, bound="latency", achieved=round(tf, 3), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
+                    frac=round(tf / PEAK_FP32_TFLOPS, 4), launch_ms=round(ms, 4),
+                    traffic=tj.get("decode8" if members == 8 else "decode"), traffic_from=traffic_from,
+                    priced_against="mfma (fp32 peak; the kernel itself uses v_pk_fma_f32 on the vector ALUs, same 157.3 TFLOP/s peak)",
+                    executed_tflops=round(run_flops / ms / 1e9, 3),
+                    frac_executed=round(run_flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4),
+                    us_per_decode_step=round(ms * 1e3 / executed_steps_holder[0], 3),
+                    note=f"per-step latency chain (two in-group L2 exchanges among {members} members + LSTM cell), not arithmetic: "
+                         "frac = algorithmic 1.835 MFLOP/token, frac_executed = the 0.786 MFLOP/token the kernel runs")
+
+    # ---- the serial pass's dominant kernel (one stream, every kernel alone on the chip)
     if dom["kernel"] == "decode":
-        run_flops = 2.0 * (4 * cfg["hidden_dim"] * cfg["hidden_dim"] * (2 * cfg["lstm_layers"] - 1)
-                           + cfg["hidden_dim"] * cfg["vocab_size"]) * B * executed_steps_holder[0]
-        roofline.update(bound="latency", kernel="decode_group_kernel", priced_against="mfma (fp32 peak; the kernel itself "
-                        "uses v_pk_fma_f32 on the vector ALUs, same 157.3 TFLOP/s peak)",
-                        executed_tflops=round(run_flops / dom["ms"] / 1e9, 3),
-                        frac_executed=round(run_flops / dom["ms"] / 1e9 / PEAK_FP32_TFLOPS, 4),
-                        us_per_decode_step=round(dom["ms"] * 1e3 / executed_steps_holder[0], 3),
-                        note="per-step latency chain (two in-group L2 exchanges + LSTM cell), not arithmetic: "
-                             "frac = algorithmic 1.835 MFLOP/token, frac_executed = the 0.786 MFLOP/token the kernel runs")
+        serial_view = decode_view("decode_group_kernel", dom["ms"], 4)
         gst = model.decoder.group_status()
         if gst is not None:     # measured placement of the last launch: L2-local exchange needs a group's 4 workgroups on one XCD
-            roofline["groups_on_one_xcd"] = f"{gst['groups_on_one_xcd']}/{gst['groups']}"
+            serial_view["groups_on_one_xcd"] = f"{gst['groups_on_one_xcd']}/{gst['groups']}"
     else:
-        roofline.update(bound="mfma")
+        serial_view = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["tflops"], peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
+                           frac=round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), launch_ms=dom["ms"], traffic=tj.get(dom["kernel"]),
+                           traffic_from=traffic_from)
+    serial_view["measured_in"] = (f"{'the timed region' if args.serial else 'a serial pass of ' + str(args.steps) + ' steps right after the timed region'}"
+                                  " (one stream, whole chip per kernel; stage marks = HIP events on that stream)")
+    schedule = None
+    timed_is_pipeline = (not args.serial) and args.coresident and pipelined_elapsed is not None and elapsed == pipelined_elapsed
+    if (not args.serial) and args.coresident:
+        # ---- the TIMED region's dominant kernel: decode_group8_kernel, from the HIP events GreedyPipeline recorded on the decode
+        # stream around each of the K launches of the timed region (the launch = a memset node of the exchange region + the
+        # kernel); beside it the encoder chain of the same region and the schedule the two streams were in
+        dec_ms = np.array([r["dec_start"].elapsed_time(r["dec_end"]) for r in pipe_trace])
+        enc_ms = np.array([r["enc_start"].elapsed_time(r["enc_end"]) for r in pipe_trace])
+        # encoder(i + 1) must start AFTER decode(i) is on the compute units; offset = its first kernel's start behind the decode launch
+        offs = np.array([a["dec_start"].elapsed_time(b["enc_start"]) for a, b in zip(pipe_trace[:-1], pipe_trace[1:])])
+        # ... and in the fast schedule the whole encoder(i + 1) ends before decode(i) does (profiles/r03/ramp.txt)
+        inside = np.array([b["enc_end"].elapsed_time(a["dec_end"]) for a, b in zip(pipe_trace[:-1], pipe_trace[1:])])
+        with torch.no_grad():     # the same kernel alone on the chip
+            enc_ = model.encoder(images)
+            for _ in range(3):
+                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8)
+            prep = model.decoder.prepare(enc_)
+            prepared = (prep[0], prep[1], prep[2], model.decoder._ws)
+            ev8 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev8[0].record()
+            for _ in range(10):
+                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8, prepared=prepared)
+            ev8[1].record()
+            torch.cuda.synchronize()
+        alone_ms = ev8[0].elapsed_time(ev8[1]) / 10
+        pipe_view = decode_view("decode_group8_kernel", float(dec_ms.mean()), 8)
+        pipe_view.update(launch_ms_min_max=[round(float(dec_ms.min()), 4), round(float(dec_ms.max()), 4)],
+                         alone_ms=round(alone_ms, 4), frac_alone=round(costs["decode"]["flops"] / alone_ms / 1e9 / PEAK_FP32_TFLOPS, 4),
+                         stretch_beside_encoder=round(float(dec_ms.mean()) / alone_ms, 3),
+                         encoder_chain_ms_in_region=round(float(enc_ms.mean()), 4),
+                         measured_in=f"the timed region: HIP events on the decode stream around each of its {len(dec_ms)} launches "
+                                     "(alone_ms: the same kernel by itself on the chip, after the region)")
+        gst = model.decoder.group_status()
+        if gst is not None:
+            pipe_view["groups_on_one_xcd"] = f"{gst['groups_on_one_xcd']}/{gst['groups']}"
+        schedule = dict(
+            held=bool(pipe.hold_encoder),
+            encoder_after_decode_launch=round(float((offs > 0).mean()), 4) if len(offs) else None,
+            encoder_inside_decode=round(float((inside > 0).mean()), 4) if len(inside) else None,
+            encoder_start_behind_decode_launch_us=[round(float(np.percentile(offs, q)) * 1e3, 1) for q in (5, 50, 95)] if len(offs) else None,
+            note="fractions of the timed batches: encoder(i+1)'s first kernel started after decode(i) was launched / the whole "
+                 "encoder(i+1) ended before decode(i) did -- 1.0 / ~1.0 is the fast schedule (conv workgroups beside a resident "
+                 "decode), anything else the slow one (profiles/r03/ramp.txt); percentiles 5 / 50 / 95 of the start offset")
+    if timed_is_pipeline:
+        roofline = pipe_view
+        roofline["serial"] = serial_view
+    else:
+        roofline = serial_view
+        if (not args.serial) and args.coresident:
+            roofline["pipelined"] = pipe_view
     enc_stages = [st for st in stages if st["kernel"].startswith("conv") or st["kernel"] == "fc"]
     if enc_stages:
         e_ms = sum(st["ms"] for st in enc_stages)
@@ -340,30 +402,11 @@ def main():
                                    frac_fp32=round(e_flops / e_ms / 1e9 / PEAK_FP32_TFLOPS, 4),
                                    frac_bf16_executed=round(6.0 * e_flops / e_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
                                    frac_bf16_executed_of_sustained=round(6.0 * e_flops / e_ms / 1e9 / SUSTAINED_BF16_TFLOPS, 4),
+                                   measured_in="the serial pass (each kernel alone on the chip)",
                                    note="algorithmic bytes / flops (SURVEY 8d); executed = 6 bf16 partial products per fp32 product; sustained = "
                                         "what bare MFMA loops reach on random operands (1.82 of the nominal 2.5 PFLOP/s)")
-    if not args.serial and args.coresident:
-        # the timed region's decode kernel, alone on the chip (in the pipelined region it shares every CU with conv workgroups)
-        with torch.no_grad():
-            enc_ = model.encoder(images)
-            for _ in range(3):
-                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8)
-            ev8 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ev8[0].record()
-            for _ in range(10):
-                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8)
-            ev8[1].record()
-            torch.cuda.synchronize()
-        roofline["timed_region_decode"] = dict(
-            kernel="decode_group8_kernel", prepare_plus_decode_alone_ms=round(ev8[0].elapsed_time(ev8[1]) / 10, 4),
-            note="8 members x 8 rows per group, one wave per SIMD and 80 KB of LDS per CU: in the timed region it shares every CU "
-                 "with the conv workgroups of the next batch; the stage times above are the SERIAL pass's (4-member kernel)")
     roofline["stages"] = stages
-    roofline["measured_in"] = ("the timed region" if args.serial else
-                               f"a serial pass of {args.steps} steps right after the timed region (one stream, whole chip per "
-                               "kernel): in the pipelined region " + ("decode_group8_kernel shares every CU with the next batch's conv "
-                               "workgroups (timed_region_decode has its time alone)" if args.coresident else
-                               "the decode runs on 128 CUs beside the encoder"))
+    roofline["stages_measured_in"] = serial_view["measured_in"]
 
     result = {
         "metric": "decoded LaTeX tokens/sec at batch 256, 320x64 imgs, seq 150",
@@ -390,12 +433,16 @@ def main():
                          f"{1 + args.pipe_decoders} streams: encoder(i+1) beside decode(i), {args.pipe_rows} rows/workgroup, "
                          f"{args.pipe_depth} batches in flight")},
         "roofline": roofline,
+        "schedule": schedule,
         "value_serial": round(total_tokens_per_step * args.steps / serial_elapsed, 1),
         "value_pipelined": None if pipelined_elapsed is None else round(total_tokens_per_step * args.steps / pipelined_elapsed, 1),
         # the same W + K batches run FIRST, straight after process start, while the GPU's clocks are still ramping up from
         # idle: what a 25 ms run measures without the settle phase (per-rank figure x ranks; not max-reduced)
         "value_cold_start": None if cold_elapsed is None else round(total_tokens_per_step * args.steps / cold_elapsed, 1),
     }
+    # what ran before the K timed batches of `value`, in batches: the cold region (W + K), the settle phase, the W warm-up steps
+    result["config"]["warmup_effective"] = (args.warmup + (args.warmup + args.steps if cold_elapsed is not None else 0)
+                                            + settled["batches"])
     result["config"]["settle"] = (f"{settled['batches']} untimed batches ({settled['ms']} ms) before the {args.warmup} warm-up steps of "
                                   "the timed region: after idle the GPU needs ~50 ms of load to reach its clocks "
                                   "(profiles/r03/ramp.txt); --settle-ms 0 turns it off") if settled["batches"] else "none"
@@ -420,6 +467,27 @@ def main():
         dist.destroy_process_group()
 
 
+def visible_gpus():
+    """GPUs this process may use, WITHOUT touching the HIP runtime in the launching parent: KFD topology nodes with SIMDs
+    (CPU nodes have simd_count 0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set."""
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(root):
+            try:
+                props = dict(l.split() for l in open(os.path.join(root, d, "properties")) if len(l.split()) == 2)
+                n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            except OSError:
+                pass
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: N child processes of this script, one rank per GPU, with the
     rendezvous variables torch.distributed.run would set (127.0.0.1, a free port).  Rank 0's stdout (the ONE JSON line)
@@ -427,7 +495,7 @@ def self_launch(n):
     I2L_DIST_BACKEND=gloo, the one-card rehearsal in which several ranks share a device."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = visible_gpus()
     if have < n and os.environ.get("I2L_DIST_BACKEND", "nccl") == "nccl":
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible; not running a smaller job under that name",
               file=sys.stderr)
@@ -838,7 +906,7 @@ def extra_modes(args, world, rank, dev, dist):
             return {"value": round(Bt * (T - 1) / min(ts_), 1), "unit": "tokens/s", "cores": torch.get_num_threads(),
                     "kind": "port", "sample": f"the full per-GPU workload (B={Bt}, T={T - 1}), autograd fwd+bwd+clip+Adam, "
                                               "dropout off, best of 2"}
-        name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "backward_streams": ("1 (--no-side-wgrad)" if args.no_side_wgrad else "3: data-gradient chain on the step's stream, weight gradients on two library side streams (I2L_FLAG_SIDE_WGRAD), joined before clip + Adam"), "parallelism": f"dp{world}: one flat-buffer all-reduce" + (" (single call)" if args.dp_single_allreduce else " (issued in two pieces, the first beside the conv backward)")}
+        name, conf = "training target tokens/sec (fwd+bwd+CE+clip+Adam)", {"workload": "cnn_lstm training step (BASELINE configs[3])", "batch_per_gpu": Bt, "global_batch": Bt * world, "seq_len": T, "dropout": 0.1, "backward_streams": ("1 (--no-side-wgrad)" if args.no_side_wgrad else "3: data-gradient chain on the step's stream, weight gradients on two side streams owned by TrainStep (i2l_lanes), joined before clip + Adam"), "parallelism": f"dp{world}: one flat-buffer all-reduce" + (" (single call)" if args.dp_single_allreduce else " (issued in two pieces, the first beside the conv backward)")}
 
     n_settle = 0
     if args.settle_ms > 0:                      # untimed: the same step until the GPU's clocks have ramped up from idle
@@ -905,7 +973,8 @@ def extra_modes(args, world, rank, dev, dist):
         # providing the encoder's time for the roofline and is a floor for `value`
         n_enc = args.pipe_encoders or 2
         pipe = GreedyPipeline(model, synth.START, synth.END, T, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8,
-                              decode_priority=args.decode_priority, encoder_streams=n_enc, stagger_us=args.pipe_stagger_us)
+                              decode_priority=args.decode_priority, encoder_streams=n_enc,
+                              hold_encoder=False if args.pipe_no_hold else None)
 
         piped_ids = [None]
 

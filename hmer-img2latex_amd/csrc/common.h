@@ -11,9 +11,20 @@
     } while (0)
 
 static inline hipStream_t i2l_s(i2l_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
-// I2L_FLAG_SIDE_WGRAD (api.hip): one of the library's side streams, made to wait for everything enqueued on `main` so far.
-// Returns nullptr when it cannot be created (the caller then stays on `main`).  i2l_side_stream_join() is the way back.
-hipStream_t i2l_side_fork(hipStream_t main, int lane);   // lane 0: decoder + FC weight gradients, lane 1: conv blocks
+// side lanes (api.hip): the caller's stream of that lane, made to wait for everything enqueued on `main` so far.
+// Returns nullptr without lanes or on a HIP error (the caller then stays on `main`).  i2l_lanes_join() is the way back.
+hipStream_t i2l_side_fork(i2l_lanes* lanes, hipStream_t main, int lane);   // lane 0: decoder + FC weight gradients, lane 1: conv blocks
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: set it once per (call site, device).  `done` is the call site's
+// function-local cache (bit d = set on device d); an idempotent cache, not a switch.
+#include <atomic>
+static inline bool i2l_lds_attr(const void* fn, size_t bytes, std::atomic<unsigned>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev >= 0 && dev < 32 && ((done.load(std::memory_order_relaxed) >> dev) & 1u)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    if (dev >= 0 && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
+    return true;
+}
 static inline int i2l_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t i2l_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

@@ -831,7 +831,7 @@ extern "C" size_t i2l_conv_bwd_workspace_bytes(int B, int Cin, int H, int W, int
 extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const float* y, const uint8_t* argmax,
                                            const float* dy, float* dx, float* dw, float* db, int B, int Cin, int H,
                                            int W, int Cout, void* workspace, size_t workspace_bytes, int flags,
-                                           i2l_stream_t stream) {
+                                           i2l_lanes* lanes, i2l_stream_t stream) {
     if (!x || !w || !y || !argmax || !dy || !dw || !db || B <= 0 || Cin <= 0 || Cout <= 0 || H < 2 || W < 2)
         return I2L_ERR_ARG;
     const bool exact = (flags & I2L_FLAG_EXACT_FP32) != 0;
@@ -874,12 +874,12 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         I2L_CHECK_LAUNCH();
     }
     if (B > 65535) return I2L_ERR_UNSUPPORTED;
-    // I2L_FLAG_SIDE_WGRAD: bias sums and the weight-gradient GEMM(s) leave the caller's stream here (their inputs -- dy,
+    // lanes != NULL: bias sums and the weight-gradient GEMM(s) leave the caller's stream here (their inputs -- dy,
     // y, x and the un-pooled gradient -- are complete on it); the data-gradient conv below stays on it.  The two use
     // disjoint workspace regions (psum / colT / gemm against wpack).
     hipStream_t sd = s;
-    if ((flags & I2L_FLAG_SIDE_WGRAD) && dx) {           // the first block (no dx) has nothing to run beside: it stays here
-        hipStream_t f = i2l_side_fork(s, 1);
+    if (lanes && dx) {                                   // the first block (no dx) has nothing to run beside: it stays here
+        hipStream_t f = i2l_side_fork(lanes, s, 1);
         if (f) sd = f;
     }
     const hipStream_t s_main = s;
@@ -892,13 +892,9 @@ extern "C" int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const 
         dim3 grid((unsigned)(B * bands), (unsigned)cbs);
 #define I2L_FIRST(CI)                                                                                                  \
         do {                                                                                                           \
-            static bool attr_done = false;                                                                             \
-            if (!attr_done) {                                                                                          \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_first_kernel<CI>),                    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)         \
-                    return I2L_ERR_LAUNCH;                                                                             \
-                attr_done = true;                                                                                      \
-            }                                                                                                          \
+            static std::atomic<unsigned> attr_done{0};           /* per device */                         \
+            if (!i2l_lds_attr(reinterpret_cast<const void*>(conv_wgrad_first_kernel<CI>), 80 * 1024, attr_done))       \
+                return I2L_ERR_LAUNCH;                                                                                 \
             hipLaunchKernelGGL(conv_wgrad_first_kernel<CI>, grid, dim3(256), first_lds, s, x, dy, y, argmax, part, H, W, \
                                Cout, Hp, Wp, bands, fast);                                                                 \
         } while (0)

@@ -987,19 +987,21 @@ namespace {
 int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
                   const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
                   int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
-                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg = 0, int flags = 0);
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg = 0, int flags = 0,
+                  uint32_t* resident_flag = nullptr, uint32_t resident_value = 0);
 }
 
 extern "C" int i2l_greedy_decode_ex(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
                                     const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
                                     float temperature, int select, int stop, int end_id, int rows_per_workgroup,
                                     int32_t* ids_out, float* logits_out, float* h_out, float* c_out, int flags,
-                                    i2l_stream_t stream) {
+                                    uint32_t* resident_flag, uint32_t resident_value, i2l_stream_t stream) {
     if (select != I2L_SELECT_LOGITS && select != I2L_SELECT_SOFTMAX) return I2L_ERR_ARG;
     if (rows_per_workgroup != 0 && rows_per_workgroup != 1 && rows_per_workgroup != 2 && rows_per_workgroup != 4)
         return I2L_ERR_ARG;
     return launch_decode(w, workspace, rows, steps, tok0, forced, h0, c0, temperature, select, stop, end_id, 0, 0.f, 0ull,
-                         ids_out, logits_out, nullptr, h_out, c_out, stream, rows_per_workgroup, flags);
+                         ids_out, logits_out, nullptr, h_out, c_out, stream, rows_per_workgroup, flags, resident_flag,
+                         resident_value);
 }
 
 extern "C" int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
@@ -1022,10 +1024,17 @@ extern "C" int i2l_sample_decode(const i2l_decoder_weights* w, const void* works
 }
 
 namespace {
+// the residency signal of a launch that does NOT run a grouped kernel (other dimensions, row-per-workgroup request): its
+// workgroups need no partners, so "resident" is said at once -- a waiter never pays its time-out for a kernel choice
+__global__ void publish_value32_kernel(unsigned* flag, unsigned value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows, int steps, const int32_t* tok0,
                   const int32_t* forced, const float* h0, const float* c0, float temperature, int select, int stop,
                   int end_id, int top_k, float top_p, unsigned long long seed, int32_t* ids_out, float* logits_out,
-                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg, int flags) {
+                  float* probs_out, float* h_out, float* c_out, i2l_stream_t stream, int rows_per_wg, int flags,
+                  uint32_t* resident_flag, uint32_t resident_value) {
     int rc = check_weights(w);
     if (rc != I2L_OK) return rc;
     if (!workspace || !tok0 || rows <= 0 || steps <= 0) return I2L_ERR_ARG;
@@ -1063,10 +1072,10 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
             gp.status = reinterpret_cast<unsigned*>(xb);
             gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
             gp.opts = group_opts(steps, flags);
+            gp.resident_flag = resident_flag; gp.resident_value = resident_value;
             hipStream_t gs = i2l_s(stream);
-            static const hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group8_kernel),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP8_LDS);
-            if (attr8 == hipSuccess) {
+            static std::atomic<unsigned> attr8{0};               // per device
+            if (i2l_lds_attr(reinterpret_cast<const void*>(decode_group8_kernel), GRP8_LDS, attr8)) {
                 if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
                 hipLaunchKernelGGL(decode_group8_kernel, dim3(i2l_cdiv(gp.n_groups, 8) * 64), dim3(G8NT), GRP8_LDS, gs, gp);
                 I2L_CHECK_LAUNCH();
@@ -1081,6 +1090,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
         gp.status = reinterpret_cast<unsigned*>(xb);
         gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
         gp.opts = group_opts(steps, flags);
+        gp.resident_flag = resident_flag; gp.resident_value = resident_value;
         hipStream_t gs = i2l_s(stream);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP_LDS) == hipSuccess) {
@@ -1089,6 +1099,10 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
             I2L_CHECK_LAUNCH();
             return I2L_OK;
         }
+    }
+    if (resident_flag) {
+        hipLaunchKernelGGL(publish_value32_kernel, dim3(1), dim3(1), 0, i2l_s(stream), resident_flag, resident_value);
+        I2L_CHECK_LAUNCH();
     }
     // rows per workgroup: fill the 256 CUs first, then stack rows (weights are streamed once per workgroup per step)
     int R = rows <= 256 ? 1 : (rows <= 512 ? 2 : 4);

@@ -66,6 +66,8 @@ struct GroupParams {
     u64_t* xchg;          // [n_groups][2][GQ][GRAN]
     unsigned* status;     // [0] != 0: a poll timed out
     GroupOpts opts;       // poll limits, exchange flavour (group_common.inc.h)
+    unsigned* resident_flag;   // may be null: receives resident_value once every group of the launch is resident
+    unsigned resident_value;
 };
 
 constexpr int DPP_SHL12 = 0x10C;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(GNT) void decode_group_kernel(GroupParams p) {
             cnt_s[3] = (all_same && !bad) ? 1 : 0;
             if (bad) cnt_s[2] = 1;
             if (m == 0 && !bad) {                            // placement statistics of the launch (read by the host on request)
-                atomicAdd(p.status + GRP_STAT_GROUPS, 1u);
+                count_resident_group(p.status, p.n_groups, p.resident_flag, p.resident_value);
                 if (all_same && !p.opts.agent_scope) atomicAdd(p.status + GRP_STAT_LOCAL, 1u);
             }
         }

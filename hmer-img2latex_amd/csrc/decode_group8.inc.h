@@ -98,7 +98,7 @@ __global__ __launch_bounds__(G8NT) void decode_group8_kernel(GroupParams p) {
             cnt_s[3] = (all_same && !bad) ? 1 : 0;
             if (bad) cnt_s[2] = 1;
             if (m == 0 && !bad) {
-                atomicAdd(p.status + GRP_STAT_GROUPS, 1u);
+                count_resident_group(p.status, p.n_groups, p.resident_flag, p.resident_value);
                 if (all_same && !p.opts.agent_scope) atomicAdd(p.status + GRP_STAT_LOCAL, 1u);
             }
         }

@@ -655,7 +655,7 @@ extern "C" size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N) {
 
 extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                                         float* dw, float* db, int M, int K, int N, int relu, void* workspace,
-                                        size_t workspace_bytes, int flags, i2l_stream_t stream) {
+                                        size_t workspace_bytes, int flags, i2l_lanes* lanes, i2l_stream_t stream) {
     if (!x || !w || !dy || !dw || (relu && !y) || M <= 0 || K <= 0 || N <= 0) return I2L_ERR_ARG;   // db may be NULL (no bias)
     if (!workspace || workspace_bytes < i2l_linear_bwd_workspace_bytes(M, K, N)) return I2L_ERR_WORKSPACE;
     hipStream_t s = i2l_s(stream);
@@ -671,11 +671,11 @@ extern "C" int i2l_linear_bias_act_bwd(const float* x, const float* w, const flo
         I2L_CHECK_LAUNCH();
         d = dpre;
     }
-    // I2L_FLAG_SIDE_WGRAD: db and dw on the library's side stream (own GEMM workspace), dx stays on the caller's
+    // lanes != NULL: db and dw on the caller's side lane 0 (own GEMM workspace), dx stays on the main stream
     hipStream_t s_main = s;
     char* gws_main = gws;
-    if ((flags & I2L_FLAG_SIDE_WGRAD) && dx) {
-        hipStream_t f = i2l_side_fork(s, 0);
+    if (lanes && dx) {
+        hipStream_t f = i2l_side_fork(lanes, s, 0);
         if (f) { s = f; gws = gws + gws_bytes; }
     }
     if (db) {

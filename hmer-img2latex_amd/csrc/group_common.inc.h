@@ -32,6 +32,15 @@ inline GroupOpts group_opts(int steps, int flags) {
 // went through the placement exchange, [2] of those, groups whose four members measured ONE XCD (L2-local stores)
 constexpr int GRP_STAT_FAILED = 0, GRP_STAT_GROUPS = 1, GRP_STAT_LOCAL = 2;
 
+// Residency signal of a grouped launch (i2l_greedy_decode_ex's resident_flag / resident_value): member 0 of every group
+// counts its group in status[GRP_STAT_GROUPS] once all members have answered the placement exchange, i.e. ARE RESIDENT; the
+// group that completes the count publishes resident_value at agent scope.  A stream that must not start before this
+// launch owns its CUs waits for the word (i2l_stream_wait_value32) -- a dependency, where r03 guessed with a 30 us delay.
+__device__ __forceinline__ void count_resident_group(unsigned* status, int n_groups, unsigned* flag, unsigned value) {
+    const unsigned before = atomicAdd(status + GRP_STAT_GROUPS, 1u);
+    if (flag && before + 1u == (unsigned)n_groups) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 
 // local == false: sc1 store (write-through to memory, seen from every XCD).  local == true (all four members were
 // found on ONE XCD): sc0 store, the line stays in that XCD's L2 where the peers' sc1 loads (L1 bypassed) find it --

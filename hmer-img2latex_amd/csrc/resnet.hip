@@ -711,10 +711,9 @@ int launch_ring4(const BfGemm& g, int nb_n, int total, hipStream_t s) {
     constexpr int lds = NS * (GM + 64 * NTW) * BK * 2;
     // once per template instantiation (a function-local static is initialised exactly once, thread-safe): the attribute
     // is a property of the kernel, not of the launch -- r02 asked the runtime again on each of the 53 launches per image batch
-    static const hipError_t attr =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES, OCC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (attr != hipSuccess) return I2L_ERR_LAUNCH;
+    static std::atomic<unsigned> attr{0};                       // ... and of the DEVICE: one bit per device
+    if (!i2l_lds_attr(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES, OCC>), lds, attr))
+        return I2L_ERR_LAUNCH;
     hipLaunchKernelGGL((gemm_bf16_ring_kernel<NTW, BK, NS, CONV, RES, OCC>), dim3(total), dim3(256), lds, s, g, nb_n, total);
     I2L_CHECK_LAUNCH();
     return I2L_OK;

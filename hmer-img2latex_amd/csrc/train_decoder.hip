@@ -593,7 +593,7 @@ TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
     o.row_loss = take(BT);
     o.row_keep = take(BT);
     o.colpart = take((size_t)1024 * (G > (size_t)V ? G : V));
-    o.colpart2 = take((size_t)1024 * (G > (size_t)V ? G : V));      // the side stream's (I2L_FLAG_SIDE_WGRAD)
+    o.colpart2 = take((size_t)1024 * (G > (size_t)V ? G : V));      // the side lane's (i2l_lanes)
     size_t g = 0;
     auto mx = [&](size_t v) { if (v > g) g = v; };
     mx(i2l_gemm_workspace_bytes((int)BT, (int)G, 2 * E));     // GX
@@ -791,7 +791,7 @@ extern "C" size_t i2l_ce_workspace_bytes(int rows) {
 extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t* tokens, int B, int T, float dropout_p,
                                       uint64_t seed, int attention_path, void* workspace, size_t workspace_bytes,
                                       const float* dlogits, const i2l_decoder_grads* gr, float* denc_out,
-                                      int flags, i2l_stream_t stream) {
+                                      int flags, i2l_lanes* lanes, i2l_stream_t stream) {
     int rc = check_w(w);
     if (rc != I2L_OK) return rc;
     const int split = (flags & I2L_FLAG_EXACT_FP32) ? 0 : 1;
@@ -807,15 +807,15 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     const size_t BT = (size_t)B * T;
     const int G = 4 * H;
     void* gws = base + lo.gemm_ws;
-    // I2L_FLAG_SIDE_WGRAD (single layer): the weight gradients and bias sums run on the library's side stream with their
+    // lanes != NULL (single layer): the weight gradients and bias sums run on the caller's side lane 0 with their
     // own GEMM workspace and column-sum scratch -- dW_out / db_out from here on, dW_ih / dW_hh / db once the recurrence's
-    // backward (on the caller's stream) has produced the gate gradients.  The caller joins (i2l_side_stream_join).
+    // backward (on the caller's stream) has produced the gate gradients.  The caller joins (i2l_lanes_join).
     hipStream_t s_w = s;
     void* gws_w = gws;
     float* colpart_w = F(lo.colpart);
-    const bool side = (flags & I2L_FLAG_SIDE_WGRAD) && L == 1;
+    const bool side = lanes != nullptr && L == 1;
     if (side) {
-        hipStream_t f = i2l_side_fork(s, 0);
+        hipStream_t f = i2l_side_fork(lanes, s, 0);
         if (f) { s_w = f; gws_w = base + lo.gemm_ws2; colpart_w = F(lo.colpart2); }
     }
 
@@ -896,7 +896,7 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
     }
     // weight gradients: one GEMM each over all B*T rows
     if (side && s_w != s) {                                  // the gate gradients are complete on the caller's stream here
-        hipStream_t f = i2l_side_fork(s, 0);
+        hipStream_t f = i2l_side_fork(lanes, s, 0);
         if (!f) return I2L_ERR_LAUNCH;
         s_w = f;
     }

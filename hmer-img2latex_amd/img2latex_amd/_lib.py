@@ -25,7 +25,6 @@ FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0
 FLAG_WEIGHTS_PACKED = 0x10          # conv forward: the workspace still holds the packed filters of these weights
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
 FLAG_CONV_NO_SPARSE_WGRAD = 0x4000   # first conv block's weight gradient by the implicit-im2col GEMM (A/B)
-FLAG_SIDE_WGRAD = 0x2000             # training backward: weight gradients on the library's side stream (join before use)
 FLAG_DECODE_GROUP8 = 0x1000          # greedy decode: 8 members x 8 rows per group (co-resident with a conv workgroup)
 FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks of the grouped kernels
 
@@ -50,18 +49,20 @@ class DecoderGrads(ctypes.Structure):
 _SIGNATURES = {
     "i2l_version": (c_int, []),
     "i2l_error_string": (c_char_p, [c_int]),
-    "i2l_side_stream_join": (c_int, [c_void_p]),
-    "i2l_stream_spin_us": (c_int, [ctypes.c_float, c_void_p]),
+    "i2l_lanes_create": (c_int, [POINTER(c_void_p), c_int, POINTER(c_void_p)]),
+    "i2l_lanes_destroy": (c_int, [c_void_p]),
+    "i2l_lanes_join": (c_int, [c_void_p, c_void_p]),
+    "i2l_stream_wait_value32": (c_int, [c_void_p, ctypes.c_uint32, ctypes.c_float, c_void_p]),
     "i2l_conv_workspace_bytes": (c_size_t, [c_int, c_int]),
     "i2l_conv3x3_relu_pool2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "i2l_conv_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "i2l_conv3x3_relu_pool2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_int,
-                                           c_void_p]),
+                                           c_void_p, c_void_p]),
     "i2l_linear_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "i2l_linear_bias_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                        c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+                                        c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "i2l_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "i2l_linear_bias_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p, c_size_t, c_int, c_void_p]),
@@ -80,7 +81,7 @@ _SIGNATURES = {
                                   c_void_p]),
     "i2l_greedy_decode_ex": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_int, c_void_p]),
+                                     c_void_p, c_int, c_void_p, ctypes.c_uint32, c_void_p]),
     "i2l_sample_decode": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                   c_int, c_float, c_uint64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
@@ -93,7 +94,8 @@ _SIGNATURES = {
     "i2l_decoder_train_fwd": (c_int, [POINTER(DecoderWeights), c_void_p, c_void_p, c_int, c_int, c_float, c_uint64,
                                       c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "i2l_decoder_train_bwd": (c_int, [POINTER(DecoderWeights), c_void_p, c_int, c_int, c_float, c_uint64, c_int,
-                                      c_void_p, c_size_t, c_void_p, POINTER(DecoderGrads), c_void_p, c_int, c_void_p]),
+                                      c_void_p, c_size_t, c_void_p, POINTER(DecoderGrads), c_void_p, c_int, c_void_p,
+                                      c_void_p]),
     "i2l_optimizer_workspace_bytes": (c_size_t, []),
     "i2l_grad_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float,
                                         c_float, c_float, c_float, c_float, c_int, c_void_p, c_size_t, c_void_p,
@@ -113,13 +115,19 @@ _SIGNATURES.update({
     "i2l_preprocess_images": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p]),
     "i2l_bn_train_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),
-    "i2l_bn_train_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                                      c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_void_p, c_size_t, c_void_p]),
-    "i2l_bn_train_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_int, ctypes.c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_bn_train_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                                     c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_bn_train_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int, ctypes.c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "i2l_conv_f32_workspace_bytes": (c_size_t, [c_int] * 11),
+    "i2l_conv_f32_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_size_t, c_int, c_void_p]),
+    "i2l_conv_f32_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 +
+                         [c_void_p, c_size_t, c_int, c_void_p]),
     "i2l_im2col_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "i2l_col2im_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
-    "i2l_maxpool3x3s2_bf16_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "i2l_maxpool3x3s2_f32_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "i2l_maxpool3x3s2_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "i2l_global_avgpool_f32_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_global_avgpool_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_decoder_group_status_offset": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "i2l_resample_ksize": (c_int, [c_int, c_int, c_int]),
@@ -190,6 +198,34 @@ def require_gpu(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
+
+
+class Lanes:
+    """Caller-owned side lanes of the training backward pass (include/img2latex_hip.h: i2l_lanes): `n` torch streams of
+    `device` plus the library's fork / join events on them.  ``handle`` goes into the ``lanes`` argument of the backward
+    entry points; ``join()`` makes the current stream wait for everything they put on the lanes."""
+
+    def __init__(self, device, n: int = 2):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        arr = (c_void_p * n)(*[s.cuda_stream for s in self.streams])
+        out = c_void_p()
+        with torch.cuda.device(device):
+            check(lib().i2l_lanes_create(arr, n, ctypes.byref(out)), "lanes_create")
+        self.handle = out.value
+
+    def join(self) -> None:
+        check(lib().i2l_lanes_join(self.handle, stream_ptr()), "lanes_join")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            lib().i2l_lanes_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pointer_array(tensors: Sequence[torch.Tensor]):

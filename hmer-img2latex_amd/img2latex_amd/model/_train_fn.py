@@ -59,11 +59,11 @@ def decoder_train_forward(decoder, enc, tokens, seed):
                         flags=int(decoder.kernel_flags))
 
 
-def decoder_train_backward(dec, state, dlogits, grads, extra_flags: int = 0):
+def decoder_train_backward(dec, state, dlogits, grads, lanes=None):
     """i2l_decoder_train_bwd: fills ``grads`` (name -> tensor, ``decoder.named_parameters()`` names;
-    attention parameters are zero-filled) and returns d(encoder_output).  ``extra_flags``: _lib.FLAG_SIDE_WGRAD puts the
-    weight gradients on the library's side stream -- the caller keeps ``state`` / ``dlogits`` alive and joins
-    (``i2l_side_stream_join``) before reading ``grads`` (TrainStep does)."""
+    attention parameters are zero-filled) and returns d(encoder_output).  ``lanes``: an ``_lib.Lanes(...).handle`` puts the
+    weight gradients on the caller's side lanes -- the caller keeps ``state`` / ``dlogits`` alive and joins
+    (``Lanes.join``) before reading ``grads`` (TrainStep does)."""
     dlogits = _lib.require_gpu(dlogits, "dlogits")
     tokens = state["tokens"]
     B, T = tokens.shape
@@ -84,7 +84,7 @@ def decoder_train_backward(dec, state, dlogits, grads, extra_flags: int = 0):
     _lib.check(L.i2l_decoder_train_bwd(ctypes.byref(w), tokens.data_ptr(), B, T, state["p"], state["seed"],
                                        1 if dec.use_attention else 0, ws.data_ptr(), ws.numel(),
                                        dlogits.data_ptr(), ctypes.byref(g), denc.data_ptr(),
-                                       state["flags"] | int(extra_flags), _lib.stream_ptr()),
+                                       state["flags"], lanes, _lib.stream_ptr()),
                "decoder_train_bwd")
     del keep
     return denc
@@ -140,7 +140,7 @@ def _resnet_train_forward(encoder, x):
     return out, tape
 
 
-def _resnet_train_backward(enc, tape, denc, grads, after_linear=None, extra_flags=0, keep=None):
+def _resnet_train_backward(enc, tape, denc, grads, after_linear=None):
     """``grads``: name -> tensor for the TRAINABLE parameters of the encoder (``named_parameters()`` names)."""
     L = _lib.lib()
     denc = _lib.require_gpu(denc, "d encoder_output")
@@ -158,7 +158,7 @@ def _resnet_train_backward(enc, tape, denc, grads, after_linear=None, extra_flag
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     _lib.check(L.i2l_linear_bias_act_bwd(feat.data_ptr(), lin.weight.detach().data_ptr(), out.data_ptr(), denc.data_ptr(),
                                          dfeat.data_ptr(), dw.data_ptr(), db.data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
-                                         0, _lib.stream_ptr()), "linear_bias_act_bwd")
+                                         0, None, _lib.stream_ptr()), "linear_bias_act_bwd")
     if after_linear is not None:
         after_linear()
     enc._trunk_backward(tape, dfeat, grads)
@@ -173,16 +173,16 @@ def encoder_train_forward(encoder, x):
     return out, dict(x=x, blocks=blocks, amax=amax, out=out)
 
 
-def encoder_train_backward(enc, state, denc, grads, after_linear=None, extra_flags: int = 0, keep=None):
+def encoder_train_backward(enc, state, denc, grads, after_linear=None, lanes=None, keep=None):
     """Fills ``grads`` (``encoder.named_parameters()`` names) from d(encoder_output).  ``after_linear`` is called once the
     FC layer's backward has been enqueued (TrainStep starts the early part of the gradient all-reduce there).
-    ``extra_flags`` = _lib.FLAG_SIDE_WGRAD (CNN encoder): weight gradients on the library's side stream; every temporary
-    they read is appended to the list ``keep``, which the caller holds until it has joined (``i2l_side_stream_join``)."""
+    ``lanes`` = an ``_lib.Lanes(...).handle`` (CNN encoder): weight gradients on the caller's side lanes; every temporary
+    they read is appended to the list ``keep``, which the caller holds until it has joined (``Lanes.join``)."""
     if hasattr(enc, "_trunk_train"):                      # ResNetEncoder (its gradient GEMMs stay on the caller's stream)
         return _resnet_train_backward(enc, state, denc, grads, after_linear)
-    side = int(extra_flags) & _lib.FLAG_SIDE_WGRAD
+    side = lanes
     if side and keep is None:
-        raise ValueError("FLAG_SIDE_WGRAD needs a `keep` list that outlives the join")
+        raise ValueError("side lanes need a `keep` list that outlives the join")
     L = _lib.lib()
     denc = _lib.require_gpu(denc, "d encoder_output")
     dev = denc.device
@@ -197,7 +197,7 @@ def encoder_train_backward(enc, state, denc, grads, after_linear=None, extra_fla
     _lib.check(L.i2l_linear_bias_act_bwd(feat.data_ptr(), lin.weight.detach().data_ptr(), state["out"].data_ptr(),
                                          denc.data_ptr(), dfeat.data_ptr(), grads["embedding_layer.weight"].data_ptr(),
                                          grads["embedding_layer.bias"].data_ptr(), B, K, E, 1, ws.data_ptr(), nbytes,
-                                         enc.kernel_flags | side, _lib.stream_ptr()), "linear_bias_act_bwd")
+                                         enc.kernel_flags, side, _lib.stream_ptr()), "linear_bias_act_bwd")
     if side:
         keep.extend((ws, denc, state))
     if after_linear is not None:
@@ -214,7 +214,7 @@ def encoder_train_backward(enc, state, denc, grads, after_linear=None, extra_fla
             xin.data_ptr(), conv.weight.detach().data_ptr(), blocks[i].data_ptr(), amax[i].data_ptr(),
             dy.data_ptr(), _lib.ptr(dx), grads[f"cnn_layers.{3 * i}.weight"].data_ptr(),
             grads[f"cnn_layers.{3 * i}.bias"].data_ptr(), B, cin, h, w, conv.out_channels, ws.data_ptr(), nbytes,
-            enc.kernel_flags | side, _lib.stream_ptr()), "conv3x3_relu_pool2_bwd")
+            enc.kernel_flags, side, _lib.stream_ptr()), "conv3x3_relu_pool2_bwd")
         if side:
             keep.extend((ws, dy))
         dy = dx

@@ -49,16 +49,20 @@ class CNNEncoder(nn.Module):
         self.flattened_size = cin * h * w              # what the reference finds by a dummy forward (:99-102)
         self.embedding_layer = nn.Linear(self.flattened_size, embedding_dim)
         self.activation = nn.ReLU()
-        self._ws: Optional[torch.Tensor] = None
-        self._packed_ws = {}       # block index -> (workspace holding the packed filters, key they were packed for)
+        # Workspaces are per (device, STREAM): GreedyPipeline(encoder_streams=2) runs two forwards of this module side by
+        # side, and the FC layer's split-K slabs / a block's packed filter image must not be shared between them
+        self._ws = {}              # (device, stream) -> scratch
+        self._packed_ws = {}       # (block index, stream) -> (workspace holding the packed filters, key they were packed for)
         self.kernel_flags = 0      # _lib.FLAG_EXACT_FP32: exact fp32 kernels instead of the 3 x bf16 split
 
     def _workspace(self, nbytes: int, device) -> Optional[torch.Tensor]:
         if nbytes == 0:
             return None
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws
+        key = (str(device), _lib.stream_ptr())
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return ws
 
     def conv_blocks(self, x: torch.Tensor, argmax_out: Optional[List[torch.Tensor]] = None) -> List[torch.Tensor]:
         """Outputs of the conv blocks (each = Conv2d+ReLU+MaxPool2d fused in one launch).
@@ -85,14 +89,15 @@ class CNNEncoder(nn.Module):
             else:
                 # inference: every block keeps its own workspace, so the packed filter image written there survives from
                 # batch to batch; it is rebuilt only when the weight changed ((data_ptr, _version), as LSTMDecoder.prepare)
-                key = (wt.data_ptr(), conv.weight._version, x.device, nbytes, self.kernel_flags, _lib.stream_ptr())
-                held = self._packed_ws.get(i)
+                key = (wt.data_ptr(), conv.weight._version, x.device, nbytes, self.kernel_flags)
+                slot = (i, _lib.stream_ptr())
+                held = self._packed_ws.get(slot)
                 if held is None or held[0].numel() < max(nbytes, 16) or held[0].device != x.device:
                     held = (torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device), None)
                 ws = held[0] if nbytes else None
                 if held[1] == key:
                     flags |= _lib.FLAG_WEIGHTS_PACKED
-                self._packed_ws[i] = (held[0], key)
+                self._packed_ws[slot] = (held[0], key)
             _lib.check(L.i2l_conv3x3_relu_pool2_fwd(x.data_ptr(), wt.data_ptr(), bs.data_ptr(), y.data_ptr(),
                                                     _lib.ptr(amax), B, cin, h, w, conv.out_channels, _lib.ptr(ws),
                                                     nbytes, flags, _lib.stream_ptr()),

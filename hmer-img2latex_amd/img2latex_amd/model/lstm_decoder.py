@@ -140,6 +140,15 @@ class LSTMDecoder(nn.Module):
         _lib.mark("prepare")
         return w, keep, enc
 
+    def release_slots(self, owner) -> None:
+        """Drop the workspaces ``prepare(slot=(..., owner, ...))`` created for ``owner`` (a pipeline's id): a pipeline that
+        goes away gives its decoder workspaces back instead of leaving them pinned on the model."""
+        for sid in [k for k in self._ws_by_stream
+                    if isinstance(k, tuple) and k[0] == "slot" and isinstance(k[1], tuple) and len(k[1]) > 1 and k[1][1] == owner]:
+            ws, _ = self._ws_by_stream.pop(sid)
+            if self._ws is ws:
+                self._ws, self._ws_key = None, None
+
     def group_status(self):
         """Diagnostics of the LAST grouped greedy launch on the current stream (synchronises): {"timed_out", "groups",
         "groups_on_one_xcd"} -- how many 4-workgroup groups ran and how many of them found their members on one XCD
@@ -158,10 +167,12 @@ class LSTMDecoder(nn.Module):
                   temperature: float = 1.0, select: int = _lib.SELECT_LOGITS, stop: int = _lib.STOP_NONE,
                   end_id: int = -1, want_ids: bool = True, want_logits: bool = False,
                   want_state: bool = False, reuse_weight_images: bool = True, rows_per_workgroup: int = 0,
-                  flags: int = 0, prepared=None):
+                  flags: int = 0, prepared=None, resident=None):
         """prepare + one persistent i2l_greedy_decode launch.  Returns (ids, logits, (h, c)).
         ``prepared`` = (w, keep, enc, workspace) of an earlier ``prepare(encoder_output, slot=...)`` whose completion the
-        current stream already waits for: the launch uses that workspace and prepares nothing."""
+        current stream already waits for: the launch uses that workspace and prepares nothing.
+        ``resident`` = (int32 device tensor, value): the launch stores ``value`` there once its workgroups own their compute
+        units (i2l_greedy_decode_ex's residency signal; GreedyPipeline's encoder stream waits for it)."""
         if prepared is None:
             w, keep, enc = self.prepare(encoder_output, reuse_weight_images)
             ws = self._ws
@@ -189,8 +200,9 @@ class LSTMDecoder(nn.Module):
         _lib.check(_lib.lib().i2l_greedy_decode_ex(
             ctypes.byref(w), ws.data_ptr(), rows, steps, tok0.data_ptr(), _lib.ptr(forced), _lib.ptr(h0),
             _lib.ptr(c0), float(temperature), select, stop, int(end_id), int(rows_per_workgroup), _lib.ptr(ids),
-            _lib.ptr(logits), _lib.ptr(h), _lib.ptr(c), int(flags) | int(self.kernel_flags), _lib.stream_ptr()),
-            "greedy_decode")
+            _lib.ptr(logits), _lib.ptr(h), _lib.ptr(c), int(flags) | int(self.kernel_flags),
+            None if resident is None else resident[0].data_ptr(), 0 if resident is None else int(resident[1]) & 0xFFFFFFFF,
+            _lib.stream_ptr()), "greedy_decode")
         _lib.mark("decode")
         del keep
         return ids, logits, ((h, c) if want_state else None)

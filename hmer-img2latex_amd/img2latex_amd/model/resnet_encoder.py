@@ -11,11 +11,12 @@ expect real weights to arrive through ``load_state_dict``.
 Inference (``.eval()``): BatchNorm uses its running statistics, folded into the conv epilogue; convolutions run
 in bf16 on the matrix cores with fp32 accumulation (BASELINE config 5).
 
-Training (``.train()``, r03): every BatchNorm2d normalises with BATCH statistics and updates its running statistics
-(also the frozen ones: ``freeze_backbone`` only clears ``requires_grad``, encoder.py:201-210); the forward keeps a tape
-(raw conv outputs, batch statistics, activations) and the backward walks it in reverse through the HIP gradient
-kernels (csrc/resnet_train.hip): BatchNorm / ReLU / residual backward, conv weight and data gradients as GEMMs over an
-explicit im2col image, max-pool and average-pool backward.  Gradients stop at the first unit that has a trainable
+Training (``.train()``, r03; fp32 grade since r04): every BatchNorm2d normalises with BATCH statistics and updates its
+running statistics (also the frozen ones: ``freeze_backbone`` only clears ``requires_grad``, encoder.py:201-210); the
+forward keeps a tape (raw conv outputs, batch statistics, activations -- all NHWC fp32, the convolutions on the
+split-bf16 matrix-core GEMM, i.e. the arithmetic of the reference's fp32 branch) and the backward walks it in reverse
+through the HIP gradient kernels (csrc/resnet_train.hip): BatchNorm / ReLU / residual backward, conv weight and data
+gradients as GEMMs over an explicit im2col image, max-pool and average-pool backward.  Gradients stop at the first unit that has a trainable
 parameter: with the default ``freeze_backbone=True`` that is layer4.
 """
 from __future__ import annotations
@@ -199,39 +200,21 @@ class ResNetEncoder(nn.Module):
         return feat
 
     # ------------------------------------------------------------------ training mode (batch statistics, backward)
-    def _identity_pack(self, conv: nn.Conv2d, device) -> torch.Tensor:
-        """bf16 filter image with an IDENTITY BatchNorm folded in: the conv launch then returns the raw z."""
-        key = ("train", conv.weight.data_ptr(), conv.weight._version)
-        hit = self._packed.get(("train", id(conv)))
-        if hit is not None and hit[0] == key and hit[1].device == device:
-            return hit[1]
-        L = _lib.lib()
-        k, co = conv.kernel_size[0], conv.out_channels
-        ident = getattr(self, "_ident", None)
-        if ident is None or ident[0].numel() < co or ident[0].device != device:
-            ident = self._ident = (torch.ones(max(co, 2048), device=device), torch.zeros(max(co, 2048), device=device))
-        one, zero = ident
-        nbytes = L.i2l_conv_bf16_packed_bytes(co, conv.in_channels, k, k)
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _lib.check(L.i2l_conv_bn_bf16_pack(conv.weight.detach().data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(),
-                                           one.data_ptr(), 0.0, buf.data_ptr(), nbytes, co, conv.in_channels, k, k,
-                                           _lib.stream_ptr()), "conv_bn_bf16_pack")
-        self._packed[("train", id(conv))] = (key, buf)
-        return buf
-
-    def _conv_bn_train(self, x, shape, conv, bn, relu, residual, nchw_f32, tape):
-        """conv -> z (bf16), batch-statistics BatchNorm (+ residual) (+ ReLU) -> y (bf16); records the unit on the tape."""
+    def _conv_bn_train(self, x, shape, conv, bn, relu, residual, nchw, tape):
+        """conv -> z, batch-statistics BatchNorm (+ residual) (+ ReLU) -> y, all NHWC fp32 (fp32-grade GEMM on the
+        split-bf16 matrix-core kernel, csrc/resnet_train.hip); records the unit on the tape."""
         B, H, W, Cin = shape
         k, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         Ho, Wo = (H + 2 * pd - k) // s + 1, (W + 2 * pd - k) // s + 1
         L = _lib.lib()
         dev, co = x.device, conv.out_channels
-        z = torch.empty((B, Ho, Wo, co), dtype=torch.bfloat16, device=dev)
-        nbytes = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, co, k, k, s, pd, self.kernel_flags)
+        kind = 2 if nchw else 1
+        z = torch.empty((B, Ho, Wo, co), dtype=torch.float32, device=dev)
+        nbytes = L.i2l_conv_f32_workspace_bytes(kind, B, H, W, Cin, co, k, k, s, pd, 0)
         ws = self._workspace(nbytes, dev)
-        _lib.check(L.i2l_conv_bn_act_bf16_fwd(x.data_ptr(), 1 if nchw_f32 else 0, self._identity_pack(conv, dev).data_ptr(),
-                                              None, z.data_ptr(), B, H, W, Cin, co, k, k, s, pd, 0, ws.data_ptr(), nbytes,
-                                              self.kernel_flags, _lib.stream_ptr()), "conv_bn_act_bf16_fwd")
+        _lib.check(L.i2l_conv_f32_fwd(x.data_ptr(), kind, conv.weight.detach().data_ptr(), z.data_ptr(), B, H, W, Cin, co,
+                                      k, k, s, pd, ws.data_ptr(), nbytes, self.kernel_flags & _lib.FLAG_EXACT_FP32,
+                                      _lib.stream_ptr()), "conv_f32_fwd")
         M = B * Ho * Wo
         y = torch.empty_like(z)
         mean = torch.empty((co,), dtype=torch.float32, device=dev)
@@ -244,16 +227,16 @@ class ResNetEncoder(nn.Module):
             bn.num_batches_tracked.add_(1)
             if bn.momentum is None:                                  # cumulative moving average (nn.BatchNorm2d)
                 momentum = 1.0 / float(bn.num_batches_tracked)
-        _lib.check(L.i2l_bn_train_fwd_bf16(z.data_ptr(), _lib.ptr(residual), bn.weight.detach().data_ptr(),
-                                           bn.bias.detach().data_ptr(), bn.running_mean.data_ptr() if track else None,
-                                           bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
-                                           1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), M, co,
-                                           ws.data_ptr(), nb, _lib.stream_ptr()), "bn_train_fwd_bf16")
+        _lib.check(L.i2l_bn_train_fwd_f32(z.data_ptr(), _lib.ptr(residual), bn.weight.detach().data_ptr(),
+                                          bn.bias.detach().data_ptr(), bn.running_mean.data_ptr() if track else None,
+                                          bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
+                                          1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), M, co,
+                                          ws.data_ptr(), nb, _lib.stream_ptr()), "bn_train_fwd_f32")
         if track:
             for t in (bn.running_mean, bn.running_var):              # written through raw pointers: packed-weight caches
                 torch.autograd.graph.increment_version(t)
         if tape is not None:
-            tape.append(dict(conv=conv, bn=bn, x=x, in_shape=shape, nchw=nchw_f32, z=z, y=y, relu=relu, mean=mean,
+            tape.append(dict(conv=conv, bn=bn, x=x, in_shape=shape, nchw=nchw, z=z, y=y, relu=relu, mean=mean,
                              invstd=invstd, out_shape=(B, Ho, Wo, co), residual=residual))
         return y, (B, Ho, Wo, co)
 
@@ -269,8 +252,8 @@ class ResNetEncoder(nn.Module):
         h, shp = self._conv_bn_train(x, (B, H, W, 3), m[0], m[1], True, None, True, units)
         Bh, Hh, Wh, Ch = shp
         Ho, Wo = (Hh - 1) // 2 + 1, (Wh - 1) // 2 + 1
-        p = torch.empty((B, Ho, Wo, Ch), dtype=torch.bfloat16, device=x.device)
-        _lib.check(L.i2l_maxpool3x3s2_bf16_fwd(h.data_ptr(), p.data_ptr(), B, Hh, Wh, Ch, _lib.stream_ptr()), "maxpool")
+        p = torch.empty((B, Ho, Wo, Ch), dtype=torch.float32, device=x.device)
+        _lib.check(L.i2l_maxpool3x3s2_f32_fwd(h.data_ptr(), p.data_ptr(), B, Hh, Wh, Ch, _lib.stream_ptr()), "maxpool")
         pool_in, pool_shape = h, shp
         h, shp = p, (B, Ho, Wo, Ch)
         blocks = []
@@ -296,7 +279,7 @@ class ResNetEncoder(nn.Module):
                     blocks.append(rec)
         Bf, Hf, Wf, Cf = shp
         feat = torch.empty((B, Cf), dtype=torch.float32, device=x.device)
-        _lib.check(L.i2l_global_avgpool_bf16_fwd(h.data_ptr(), feat.data_ptr(), B, Hf, Wf, Cf, _lib.stream_ptr()), "avgpool")
+        _lib.check(L.i2l_global_avgpool_f32_fwd(h.data_ptr(), feat.data_ptr(), B, Hf, Wf, Cf, _lib.stream_ptr()), "avgpool")
         if tape is not None:
             tape.update(units=units, blocks=blocks, pool_in=pool_in, pool_shape=pool_shape, final_shape=shp)
         return feat
@@ -307,29 +290,19 @@ class ResNetEncoder(nn.Module):
         conv = u["conv"]
         B, H, W, Cin = u["in_shape"]
         k, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        _, Ho, Wo, co = u["out_shape"]
-        M, Kc = B * Ho * Wo, Cin * k * k
+        co = u["out_shape"][3]
         dev = dz.device
         want_dw = conv.weight.requires_grad
         if not (want_dw or need_dx):
             return None
-        col = torch.empty((M, Kc), dtype=torch.float32, device=dev)
-        _lib.check(L.i2l_im2col_f32(u["x"].data_ptr(), 2 if u["nchw"] else 0, B, H, W, Cin, k, k, s, pd, col.data_ptr(),
-                                    _lib.stream_ptr()), "im2col_f32")
-        dw = grads[name + ".weight"] if want_dw else torch.empty((co, Kc), dtype=torch.float32, device=dev)
-        dcol = torch.empty((M, Kc), dtype=torch.float32, device=dev) if need_dx else None
-        nbytes = L.i2l_linear_bwd_workspace_bytes(M, Kc, co)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(L.i2l_linear_bias_act_bwd(col.data_ptr(), conv.weight.detach().data_ptr(), None, dz.data_ptr(),
-                                             _lib.ptr(dcol), dw.data_ptr(), None, M, Kc, co, 0, ws.data_ptr(),
-                                             nbytes, 0, _lib.stream_ptr()), "conv gradient GEMMs")
-        if not need_dx:
-            return None
-        if k == 1 and s == 1:
-            return dcol.view(B, H, W, Cin)
-        dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
-        _lib.check(L.i2l_col2im_f32(dcol.data_ptr(), B, H, W, Cin, k, k, s, pd, dx.data_ptr(), 0, _lib.stream_ptr()),
-                   "col2im_f32")
+        kind = 2 if u["nchw"] else 1
+        dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev) if need_dx else None
+        nbytes = L.i2l_conv_f32_workspace_bytes(kind, B, H, W, Cin, co, k, k, s, pd, 1 if need_dx else 0)
+        ws = self._workspace(nbytes, dev)
+        _lib.check(L.i2l_conv_f32_bwd(u["x"].data_ptr(), kind, conv.weight.detach().data_ptr(), dz.data_ptr(), _lib.ptr(dx),
+                                      grads[name + ".weight"].data_ptr() if want_dw else None, B, H, W, Cin, co, k, k, s, pd,
+                                      ws.data_ptr(), nbytes, self.kernel_flags & _lib.FLAG_EXACT_FP32, _lib.stream_ptr()),
+                   "conv_f32_bwd")
         return dx
 
     def _unit_backward(self, u, dy, need_dx, grads, names, dres=None, dres_accumulate=False):
@@ -341,14 +314,14 @@ class ResNetEncoder(nn.Module):
         nm_conv, nm_bn = names[id(u["conv"])], names[id(bn)]
         dz = torch.empty((B, Ho, Wo, co), dtype=torch.float32, device=dy.device)
         nb = L.i2l_bn_train_workspace_bytes(M, co)
-        ws = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+        ws = self._workspace(nb, dy.device)
         dgamma = grads[nm_bn + ".weight"] if bn.weight.requires_grad else None
         dbeta = grads[nm_bn + ".bias"] if bn.bias.requires_grad else None
-        _lib.check(L.i2l_bn_train_bwd_bf16(dy.data_ptr(), u["y"].data_ptr() if u["relu"] else None, u["z"].data_ptr(),
+        _lib.check(L.i2l_bn_train_bwd_f32(dy.data_ptr(), u["y"].data_ptr() if u["relu"] else None, u["z"].data_ptr(),
                                            bn.weight.detach().data_ptr(), u["mean"].data_ptr(), u["invstd"].data_ptr(),
                                            dz.data_ptr(), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dres),
                                            1 if dres_accumulate else 0, M, co, ws.data_ptr(), nb, _lib.stream_ptr()),
-                   "bn_train_bwd_bf16")
+                   "bn_train_bwd_f32")
         dx = self._conv_backward(u, dz, need_dx, grads, nm_conv)
         if self.trace_bwd is not None:
             self.trace_bwd.append(dict(unit=u, dy=dy, dz=dz, dx=dx, dres=dres, conv_name=nm_conv, bn_name=nm_bn))
@@ -394,7 +367,7 @@ class ResNetEncoder(nn.Module):
         if first_trainable == 0:
             Bp, Hp, Wp, Cp = tape["pool_shape"]
             dpool = torch.empty((Bp, Hp, Wp, Cp), dtype=torch.float32, device=dfeat.device)
-            _lib.check(L.i2l_maxpool3x3s2_bf16_bwd(tape["pool_in"].data_ptr(), dh.data_ptr(), dpool.data_ptr(), Bp, Hp, Wp, Cp,
+            _lib.check(L.i2l_maxpool3x3s2_f32_bwd(tape["pool_in"].data_ptr(), dh.data_ptr(), dpool.data_ptr(), Bp, Hp, Wp, Cp,
                                                    _lib.stream_ptr()), "maxpool3x3s2_bwd")
             self._unit_backward(units[0], dpool, False, grads, names)
 

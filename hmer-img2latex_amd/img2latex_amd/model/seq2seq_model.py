@@ -73,10 +73,10 @@ class Seq2SeqModel(nn.Module):
 
     def greedy_ids(self, encoder_output: torch.Tensor, start_token_id: int, end_token_id: int, max_length: int,
                    temperature: float = 1.0, stop: int = _lib.STOP_NONE, select: int = _lib.SELECT_LOGITS,
-                   want_logits: bool = False, rows_per_workgroup: int = 0, flags: int = 0, prepared=None):
+                   want_logits: bool = False, rows_per_workgroup: int = 0, flags: int = 0, prepared=None, resident=None):
         """Device-side greedy loop; returns (ids (B,T) int32 on device, logits or None).  ``flags``:
         _lib.FLAG_DECODE_GROUP8 selects the 8-member grouped kernel (the one that shares a CU with a conv workgroup);
-        ``prepared``: see LSTMDecoder.run_steps."""
+        ``prepared`` / ``resident``: see LSTMDecoder.run_steps."""
         B = encoder_output.shape[0]
         key = (B, int(start_token_id), encoder_output.device)
         if getattr(self, "_tok0_key", None) != key:               # the START column: built once per batch shape
@@ -86,7 +86,7 @@ class Seq2SeqModel(nn.Module):
         ids, logits, _ = self.decoder.run_steps(encoder_output, max_length, tok0, temperature=temperature,
                                                 select=select, stop=stop, end_id=end_token_id,
                                                 want_logits=want_logits, rows_per_workgroup=rows_per_workgroup,
-                                                flags=flags, prepared=prepared)
+                                                flags=flags, prepared=prepared, resident=resident)
         return ids, logits
 
     def greedy_ids_host(self, encoder_output: torch.Tensor, start_token_id: int, end_token_id: int, max_length: int,

@@ -1,13 +1,16 @@
 """Two-stage batch pipeline for greedy inference on one GPU.
 
-Images are independent, so consecutive batches can overlap: the encoder of batch i+1
-(fp32-MFMA bound, thousands of short workgroups) runs on one HIP stream while the
-persistent decode loop of batch i runs on another.  A decode workgroup owns its CU (it keeps
-~500 registers per lane of weights resident), so the decode is launched with TWO rows per
-workgroup: 128 workgroups on 128 CUs at nearly the same time per step (the weight stream of a
-workgroup is shared by its rows), which leaves the other 128 CUs to the encoder.  Steady-state
-time per batch approaches max(encoder on half the chip, decode on half the chip) instead of the
-sum on the whole chip.
+Images are independent, so consecutive batches can overlap: the encoder of batch i + 1 runs on one HIP stream while the
+persistent decode loop of batch i runs on another.  Two ways of sharing the chip are built:
+
+* co-resident (r03, what bench.py times and Predictor uses): ``decode_flags = FLAG_DECODE_GROUP8`` -- the 8-member grouped
+  decode keeps one wave per SIMD and 80 KB of LDS on EVERY compute unit, which leaves room for one conv workgroup of the
+  next batch's encoder on the same unit: the two kernels share the chip by resource.  The encoder of batch i + 1 is held
+  back until the decode of batch i owns its compute units -- a DEPENDENCY since r04: the decode kernel publishes a
+  sequence number once all its groups are resident (i2l_greedy_decode_ex's residency signal) and the encoder stream
+  waits for that word (i2l_stream_wait_value32); r03 guessed the moment with a 30 us delay kernel;
+* by compute-unit count (r01, ``rows_per_workgroup = 2``): a row-per-workgroup decode on 128 units, the encoder on the
+  other 128.  2.6x slower than the grouped kernels; kept for decoders the grouped kernels do not cover.
 
 Nothing is skipped: every batch still runs the full encoder, decoder prepare, decode loop
 and id copy; results equal ``Seq2SeqModel._greedy_search`` batch by batch.
@@ -28,8 +31,8 @@ class GreedyPipeline:
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
                  decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1,
-                 encoder_priority: int = 0, stagger_us: Optional[float] = None, stop: int = _lib.STOP_NONE,
-                 select: int = _lib.SELECT_LOGITS):
+                 encoder_priority: int = 0, hold_encoder: Optional[bool] = None, wait_timeout_us: float = 20000.0,
+                 stop: int = _lib.STOP_NONE, select: int = _lib.SELECT_LOGITS):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
         dev = next(model.parameters()).device
@@ -52,18 +55,23 @@ class GreedyPipeline:
         self.decode_flags = int(decode_flags)
         self.stop, self.select = int(stop), int(select)   # STOP_STICKY + SELECT_SOFTMAX = Predictor.predict_batch's loop
         self.encoder_flags = int(encoder_flags)          # e.g. _lib.FLAG_CONV_ONE_PER_CU while the pipeline runs
-        # Co-resident mode with one encoder stream: the encoder of batch i + 1 is held back until the decode of batch i has been
-        # LAUNCHED (event recorded after its prepare) plus `stagger_us` of idling on the encoder stream, so that the decode's
-        # 256 workgroups are resident before the first conv workgroup asks for a CU.  Launched the other way round -- conv0 of
-        # batch i + 1 beside prepare(i), conv1 racing the decode for CUs -- the two kernels fall into a schedule in which conv1
-        # crawls for the whole decode and conv2 / FC follow alone: 1.25 - 1.45 ms per batch instead of 1.07.  Left alone the
-        # pipeline drifts out of that schedule within 5 - 45 batches (profiles/r03/ramp.txt); with the stagger it never enters it.
-        # With n encoder streams the encoder of batch j waits for the launch of decode(j - n): every encoder starts at a decode
-        # launch, n of them in flight.
-        if stagger_us is None:
-            stagger_us = 30.0 if (self.decode_flags & _lib.FLAG_DECODE_GROUP8) else 0.0
-        self.stagger_us = float(stagger_us)
-        self._launch_evs: Deque[torch.cuda.Event] = deque(maxlen=len(self.enc_streams))
+        # Co-resident mode: the encoder of batch i + 1 is held back until the decode of batch i is RESIDENT, so that the
+        # decode's 256 workgroups are on the compute units before the first conv workgroup asks for one.  Launched the other
+        # way round -- conv0 of batch i + 1 beside prepare(i), conv1 racing the decode for CUs -- the two kernels fall into a
+        # schedule in which conv1 crawls for the whole decode and conv2 / FC follow alone: 1.25 - 1.45 ms per batch instead of
+        # 1.07 (profiles/r03/ramp.txt).  The decode launch of batch j publishes j + 1 to `_resident` when its last group has
+        # passed the placement exchange; with n encoder streams the encoder of batch j waits for the value of decode(j - n):
+        # every encoder starts at a decode's residency, n of them in flight.  `hold_encoder=False` switches the wait off (A/B);
+        # `wait_timeout_us` bounds it (a launch that fell back to an ungrouped kernel publishes at once, a timed-out group
+        # never does).
+        if hold_encoder is None:
+            hold_encoder = bool(self.decode_flags & _lib.FLAG_DECODE_GROUP8)
+        self.hold_encoder = bool(hold_encoder)
+        self.wait_timeout_us = float(wait_timeout_us)
+        self._resident = torch.zeros(1, dtype=torch.int32, device=dev)
+        # measurement hook (bench.py): a list here receives, per submitted batch, the timing events {"enc_start" (behind the
+        # wait), "enc_end" (behind prepare), "dec_start", "dec_end" (around the decode launch on ITS stream)}
+        self.trace: Optional[list] = None
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor, torch.Tensor]] = deque()
         self.copy_stream = torch.cuda.Stream(device=dev)     # the ids' device -> host copies (off the decode stream: +1 %)
         self._batch_no = 0
@@ -81,9 +89,16 @@ class GreedyPipeline:
         enc_stream.wait_stream(cur)                           # images were produced on the caller's stream
         with torch.no_grad():
             with torch.cuda.stream(enc_stream):
-                if self.stagger_us > 0 and len(self._launch_evs) == self._launch_evs.maxlen:
-                    enc_stream.wait_event(self._launch_evs[0])     # launch of decode(j - n)
-                    _lib.check(_lib.lib().i2l_stream_spin_us(self.stagger_us, _lib.stream_ptr()), "stream_spin_us")
+                if self.hold_encoder and self._batch_no >= len(self.enc_streams):
+                    # decode(j - n) is resident <=> the word has reached (j - n) + 1
+                    _lib.check(_lib.lib().i2l_stream_wait_value32(
+                        self._resident.data_ptr(), self._batch_no - len(self.enc_streams) + 1, self.wait_timeout_us,
+                        _lib.stream_ptr()), "stream_wait_value32")
+                rec = None
+                if self.trace is not None:
+                    rec = {k: torch.cuda.Event(enable_timing=True) for k in ("enc_start", "enc_end", "dec_start", "dec_end")}
+                    rec["enc_start"].record(enc_stream)
+                    self.trace.append(rec)
                 saved = self.model.encoder.kernel_flags
                 self.model.encoder.kernel_flags = saved | self.encoder_flags
                 try:
@@ -94,10 +109,11 @@ class GreedyPipeline:
                 # layer, into one of `depth + 1` workspaces: the decode stream then goes from decode(i) straight into
                 # decode(i + 1) (the two small prepare launches used to sit between them, ~50 us per batch)
                 slot = self._batch_no % self._slots
+                seq = self._batch_no + 1
                 self._batch_no += 1
                 w, keep, enc_c = self.model.decoder.prepare(enc, slot=("pipe", id(self), slot))
                 prepared = (w, keep, enc_c, self.model.decoder._ws)
-                enc_done = torch.cuda.Event()
+                enc_done = torch.cuda.Event() if rec is None else rec["enc_end"]
                 enc_done.record(enc_stream)
             images.record_stream(enc_stream)
             dec_stream = self.dec_streams[self._next_dec]
@@ -105,14 +121,15 @@ class GreedyPipeline:
             with torch.cuda.stream(dec_stream):
                 dec_stream.wait_event(enc_done)
                 enc.record_stream(dec_stream)
-                if self.stagger_us > 0:                            # the decode kernel is the next launch on this stream
-                    ev = torch.cuda.Event()
-                    ev.record(dec_stream)
-                    self._launch_evs.append(ev)
+                if rec is not None:
+                    rec["dec_start"].record(dec_stream)
                 ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
                                                stop=self.stop, select=self.select,
                                                rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags,
-                                               prepared=prepared)
+                                               prepared=prepared,
+                                               resident=(self._resident, seq) if self.hold_encoder else None)
+                if rec is not None:
+                    rec["dec_end"].record(dec_stream)
                 host = self._host_buffer(ids.shape)
                 if self.copy_stream is None:
                     host.copy_(ids, non_blocking=True)
@@ -128,6 +145,19 @@ class GreedyPipeline:
                         done.record(self.copy_stream)
                     ids.record_stream(self.copy_stream)
         self._inflight.append((done, host, enc))
+
+    def close(self) -> None:
+        """Give the decoder workspaces of this pipeline's slots back (they live in the decoder's cache under this
+        pipeline's id); called by Predictor.predict_ids_stream when its stream ends, and on garbage collection."""
+        dec = getattr(getattr(self, "model", None), "decoder", None)
+        if dec is not None and hasattr(dec, "release_slots"):
+            dec.release_slots(id(self))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _host_buffer(self, shape) -> torch.Tensor:
         for i, t in enumerate(self._free):

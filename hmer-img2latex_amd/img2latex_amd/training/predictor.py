@@ -212,12 +212,15 @@ class Predictor:
             lens = np.where(stop.any(axis=1), stop.argmax(axis=1), a.shape[1]).tolist()
             return [[start] + row[:n] for row, n in zip(a.tolist(), lens)]
 
-        for images in batches:
-            if pipe.pending() >= pipe.depth:
+        try:
+            for images in batches:
+                if pipe.pending() >= pipe.depth:
+                    yield finish(pipe.collect())
+                pipe.submit(self._as_batch(images))
+            while pipe.pending():
                 yield finish(pipe.collect())
-            pipe.submit(self._as_batch(images))
-        while pipe.pending():
-            yield finish(pipe.collect())
+        finally:
+            pipe.close()                                     # gives its decoder workspaces back
 
     def evaluate_batch(self, images, targets: torch.Tensor, max_length: Optional[int] = None) -> Dict:
         """One batch of the reference's ``evaluate`` command (cli.py:449-495) with every stage on the device and
@@ -283,7 +286,7 @@ class Predictor:
             if "enc" not in st:
                 st["enc"] = torch.cuda.Stream(self.device)
                 st["dec"] = torch.cuda.Stream(self.device, priority=-1)
-                st["launched"], st["n"] = None, 0
+                st["resident"], st["n"] = torch.zeros(1, dtype=torch.int32, device=self.device), 0
             s_enc, s_dec = st["enc"], st["dec"]
             s_enc.wait_stream(cur)                           # the caller's tensors, tgt, the constants
             on_enc = lambda: torch.cuda.stream(s_enc)
@@ -291,9 +294,9 @@ class Predictor:
         else:
             on_enc = on_dec = contextlib.nullcontext
         with on_enc():
-            if coresident and st["launched"] is not None:    # not before the previous batch's decode has been launched
-                s_enc.wait_event(st["launched"])
-                _lib.check(L.i2l_stream_spin_us(30.0, _lib.stream_ptr()), "stream_spin_us")
+            if coresident and st["n"] > 0:                   # not before the previous batch's decode owns its compute units
+                _lib.check(L.i2l_stream_wait_value32(st["resident"].data_ptr(), st["n"], 20000.0, _lib.stream_ptr()),
+                           "stream_wait_value32")
             if not isinstance(images, torch.Tensor):
                 from ..data import preprocess_batch
                 enc_mod = self.model.encoder
@@ -325,14 +328,13 @@ class Predictor:
                 s_dec.wait_event(enc_done)
                 for t_ in (x, tgt, t_ids, t_len, enc):
                     t_.record_stream(s_dec)                  # allocated on the first stream, read on the second
-                st["launched"] = torch.cuda.Event()
-                st["launched"].record(s_dec)                 # the decode kernel is the next launch on this stream
             p_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
             p_len = torch.empty((B,), dtype=torch.int32, device=dev)
             with torch.no_grad():
                 ids, _ = self.model.greedy_ids(enc, tk.start_token_id, tk.end_token_id, T, stop=_lib.STOP_STICKY,
                                                select=_lib.SELECT_SOFTMAX, rows_per_workgroup=rows_per_workgroup,
-                                               flags=_lib.FLAG_DECODE_GROUP8 if coresident else 0, prepared=prepared)
+                                               flags=_lib.FLAG_DECODE_GROUP8 if coresident else 0, prepared=prepared,
+                                               resident=(st["resident"], st["n"]) if coresident else None)
                 _lib.check(L.i2l_compact_ids(ids.data_ptr(), B, T, ids.stride(0), int(tk.end_token_id),
                                              self._drop.data_ptr(), len(drop), p_ids.data_ptr(), W, p_len.data_ptr(),
                                              _lib.stream_ptr()), "compact_ids")

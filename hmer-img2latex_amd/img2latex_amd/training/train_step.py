@@ -74,10 +74,12 @@ class TrainStep:
         # north_star's wording); True (default): the same element-wise sums issued in two pieces, the first -- everything
         # but the conv gradients -- as soon as the FC backward is enqueued, beside ~1 ms of conv backward (dp.py)
         self.overlap_all_reduce = bool(overlap_all_reduce)
-        # weight gradients on the library's side stream beside the data-gradient chain (csrc/api.hip, I2L_FLAG_SIDE_WGRAD);
-        # False keeps the whole backward on one stream (same kernels, same sums either way)
+        # weight gradients on two side streams OWNED BY THIS OBJECT beside the data-gradient chain (csrc/api.hip: i2l_lanes;
+        # r03 used streams hidden inside the library); False keeps the whole backward on one stream (same kernels, same
+        # sums either way)
         self.side_wgrad = bool(side_wgrad)
-        self._side_keep = []          # buffers the side stream's kernels still read; released after the join
+        self._lanes = _lib.Lanes(dev, 2) if self.side_wgrad else None
+        self._side_keep = []          # buffers the side lanes' kernels still read; released after the join
         self._ar_stream = None        # helper stream the early all-reduce piece is issued from (data parallel only)
         self._reducer = OverlappedAllReduce(self.flat_grads, self.n_early, self.group)
         L = _lib.lib()
@@ -108,13 +110,12 @@ class TrainStep:
                                                  self.flat_grads.data_ptr() + 4 * self.n, _lib.stream_ptr()),
                    "ce_label_smooth_fwd_bwd")
         dgr = {n[len("decoder."):]: g for n, g in self.grad_views.items() if n.startswith("decoder.")}
-        # weight gradients feed nothing in the backward chain: they go to the library's side stream (FLAG_SIDE_WGRAD) and
-        # fill the launch gaps and tile tails of the data-gradient chain; the join at the end of this method orders them
-        # before the all-reduce / Adam.
-        # Everything those kernels read is held in _side_keep until then.
-        side = _lib.FLAG_SIDE_WGRAD if self.side_wgrad else 0
+        # weight gradients feed nothing in the backward chain: they go to this object's side lanes and fill the launch
+        # gaps and tile tails of the data-gradient chain; the join at the end of this method orders them before the
+        # all-reduce / Adam.  Everything those kernels read is held in _side_keep until then.
+        side = self._lanes.handle if self.side_wgrad else None
         self._join_side()                                            # a previous forward_backward() without apply()
-        denc = decoder_train_backward(model.decoder, dec_state, dlogits, dgr, extra_flags=side)
+        denc = decoder_train_backward(model.decoder, dec_state, dlogits, dgr, lanes=side)
         if side:
             self._side_keep.extend((dec_state, dlogits, enc_state, images, tokens_in))
         egr = {n[len("encoder."):]: g for n, g in self.grad_views.items() if n.startswith("encoder.")}
@@ -133,18 +134,18 @@ class TrainStep:
                 self._ar_stream = torch.cuda.Stream(device=self.flat_grads.device)
             self._ar_stream.wait_stream(main)
             with torch.cuda.stream(self._ar_stream):
-                _lib.check(_lib.lib().i2l_side_stream_join(_lib.stream_ptr()), "side_stream_join")
+                self._lanes.join()
                 self._reducer.start_early()
         encoder_train_backward(model.encoder, enc_state, denc, egr,
-                               after_linear=after_linear if self.overlap_all_reduce else None, extra_flags=side,
+                               after_linear=after_linear if self.overlap_all_reduce else None, lanes=side,
                                keep=self._side_keep)
         self._join_side()          # flat_grads is complete for whatever the current stream does next (all-reduce, Adam, a reader)
         return logits
 
     def _join_side(self, clear: bool = True) -> None:
-        """The current stream waits for the side stream's weight gradients (no-op when none are pending)."""
+        """The current stream waits for the side lanes' weight gradients (no-op when none are pending)."""
         if self._side_keep:
-            _lib.check(_lib.lib().i2l_side_stream_join(_lib.stream_ptr()), "side_stream_join")
+            self._lanes.join()
             if clear:
                 # the buffers may be reused by later work on this stream only: that work is ordered after the join
                 self._side_keep = []

@@ -18,7 +18,10 @@
  *     never aborts; no global state (thread-compatible): the library reads no
  *     environment variable and keeps nothing between calls -- where an entry
  *     point has more than one kernel behind it, the choice is the explicit
- *     `flags` argument (I2L_FLAG_*, 0 = automatic).
+ *     `flags` argument (I2L_FLAG_*, 0 = automatic); streams and events used
+ *     beside `stream` live in caller-owned objects (i2l_lanes).  The only
+ *     file-scope data are function-local "attribute already set on device d"
+ *     bit masks (an idempotent cache of hipFuncSetAttribute).
  *   - tensors are row-major with the reference's (PyTorch) shapes.
  */
 #ifndef IMG2LATEX_HIP_H
@@ -68,25 +71,36 @@ typedef void* i2l_stream_t;
                                           batch's encoder fits beside it; same ids                                   */
 #define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
                                           implicit-im2col GEMM instead of the sparse first-block kernel (A/B, tests)   */
-#define I2L_FLAG_SIDE_WGRAD 0x2000     /* i2l_decoder_train_bwd, i2l_linear_bias_act_bwd, i2l_conv3x3_relu_pool2_bwd: the WEIGHT
-                                          gradients (and bias sums) are enqueued on the library's side stream, forked from
-                                          `stream` where their inputs are ready, beside the data-gradient chain that stays
-                                          on `stream`.  The caller must call i2l_side_stream_join(stream) before anything
-                                          reads those gradients, and keep every buffer passed to the call (workspace,
-                                          activations, dy) alive until then.  Same kernels, same sums: results identical */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
 
 int i2l_version(void);
 const char* i2l_error_string(int code);
-/* Makes `stream` wait for everything the backward entry points enqueued on the library's side stream under
- * I2L_FLAG_SIDE_WGRAD (a no-op when nothing was).  The reference has no counterpart: its autograd engine orders
- * `loss.backward()` (trainer.py:337) before `optimizer.step()` (trainer.py:343) by itself; here the caller of the
- * backward entry points states that order once per step. */
-int i2l_side_stream_join(i2l_stream_t stream);
-/* Enqueues a one-wave kernel that idles for `microseconds` (<= 10000) on `stream`: GreedyPipeline's stagger between the launch
- * of decode(i) and the first kernel of encoder(i + 1) (no counterpart in the reference, which runs one batch at a time,
- * predictor.py:205-381). */
-int i2l_stream_spin_us(float microseconds, i2l_stream_t stream);
+/* Side lanes of the training backward pass (caller-owned; the library itself keeps no state, see the header comment).
+ * i2l_decoder_train_bwd, i2l_linear_bias_act_bwd and i2l_conv3x3_relu_pool2_bwd take an `i2l_lanes* lanes` argument.
+ * NULL: everything is enqueued on `stream`.  Otherwise the WEIGHT gradients (and bias sums) -- which nothing in the
+ * backward chain consumes -- are enqueued on the caller's side streams (lane 0: decoder + Linear, lane 1: conv blocks;
+ * with one lane both share it), forked from `stream` by an event at the point where their inputs are complete, beside
+ * the data-gradient chain that stays on `stream`.  The caller must call i2l_lanes_join(lanes, stream) before anything
+ * reads those gradients and keep every buffer passed to the calls (workspace, activations, dy) alive until then.  Same
+ * kernels, same sums: results identical to lanes == NULL.  The reference has no counterpart: its autograd engine orders
+ * `loss.backward()` (trainer.py:337) before `optimizer.step()` (trainer.py:343) by itself.
+ *   create:  `streams` = n (1..I2L_MAX_LANES) non-default streams of the CURRENT device, owned by the caller and alive as
+ *            long as the object; the object adds the events it records on them
+ *   destroy: releases the events (not the streams); NULL is accepted
+ * One object serves one host thread at a time (like a stream's enqueue order, its fork / join events are not re-entrant);
+ * two threads training on one device create one each. */
+#define I2L_MAX_LANES 4
+typedef struct i2l_lanes i2l_lanes;
+int i2l_lanes_create(const i2l_stream_t* streams, int n, i2l_lanes** out);
+int i2l_lanes_destroy(i2l_lanes* lanes);
+int i2l_lanes_join(i2l_lanes* lanes, i2l_stream_t stream);
+/* Enqueues a one-wave kernel on `stream` that returns once (int32)(*flag - value) >= 0 -- `flag` a caller-owned device word
+ * -- or after timeout_us (<= 100000) microseconds, whichever comes first.  GreedyPipeline's dependency between decode(i)
+ * and encoder(i + 1): i2l_greedy_decode_ex publishes `resident_value` to `resident_flag` once the grouped decode kernel's
+ * workgroups are all resident, and the encoder stream waits for it here, so that the conv workgroups never get onto the
+ * compute units before the decode's (no counterpart in the reference, which runs one batch at a time,
+ * predictor.py:205-381).  The wait is bounded, so a signal that never comes costs time, never a hang. */
+int i2l_stream_wait_value32(const uint32_t* flag, uint32_t value, float timeout_us, i2l_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Encoder (reference img2latex/model/encoder.py)
@@ -121,7 +135,7 @@ size_t i2l_conv_bwd_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int i2l_conv3x3_relu_pool2_bwd(const float* x, const float* w, const float* y, const uint8_t* argmax,
                                const float* dy, float* dx, float* dw, float* db, int B, int Cin, int H,
                                int W, int Cout, void* workspace, size_t workspace_bytes, int flags,
-                               i2l_stream_t stream);
+                               i2l_lanes* lanes, i2l_stream_t stream);
 
 /* y = act(x @ w^T + bias): nn.Flatten + nn.Linear + nn.ReLU, encoder.py:105-107,125-127
  * (also nn.Linear(Hd->V), decoder.py:90).  x (M,K)  w (N,K)  bias (N) or NULL  y (M,N).
@@ -136,7 +150,7 @@ int i2l_linear_bias_act_fwd(const float* x, const float* w, const float* bias, f
 size_t i2l_linear_bwd_workspace_bytes(int M, int K, int N);
 int i2l_linear_bias_act_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                             float* dw, float* db, int M, int K, int N, int relu, void* workspace,
-                            size_t workspace_bytes, int flags, i2l_stream_t stream);
+                            size_t workspace_bytes, int flags, i2l_lanes* lanes, i2l_stream_t stream);
 
 /* ResNet encoder building blocks (reference encoder.py:132-249: torchvision ResNet trunk at :242),
  * inference, bf16 on the matrix cores with fp32 accumulation.  Activations are NHWC bf16 (void*).
@@ -167,33 +181,52 @@ int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H, int W, in
 /* ResNet encoder in TRAINING mode (encoder.py:185-249 under model.train(): every BatchNorm2d of the torchvision trunk
  * normalises with batch statistics and updates its running statistics -- the frozen ones too, freeze_backbone only
  * clears requires_grad, :201-210 -- and layer4 + the Linear, or with freeze_backbone=False every layer, get gradients).
- * The convolutions run on i2l_conv_bn_act_bf16_fwd with an identity BatchNorm (raw conv output z, NHWC bf16 = a
- * row-major (M = B*H*W, C) matrix, C % 8 == 0); gradients are fp32 NHWC.
- *   fwd: mean / biased variance of z per channel; running_* (may both be NULL) <- (1 - momentum) * running + momentum *
- *        (mean, UNBIASED variance); y = act(bf16(gamma * (z - mean) * invstd + beta) + residual); save_mean / save_invstd (C)
+ * fp32 GRADE throughout, as the reference's fp32 branch (trainer.py:334-343): activations, raw conv outputs z and
+ * gradients are NHWC fp32 = row-major (M = B*H*W, C) matrices; the convolutions are GEMMs on the split-bf16
+ * matrix-core kernel (3 bf16 pieces per operand, fp32 accumulation; I2L_FLAG_EXACT_FP32: fp32 MFMA).
+ *
+ * Convolution without bias (torchvision's convs have none): x_kind 1 = NHWC fp32 (B,H,W,Cin), 2 = NCHW fp32 (the image
+ * batch of the stem); w (Cout,Cin,kh,kw) fp32 as stored by nn.Conv2d; z / dz (B,Ho,Wo,Cout) NHWC fp32.
+ *   fwd: z = conv(x, w)
+ *   bwd: dw (Cout,Cin,kh,kw) = d/dw, dx (B,H,W,Cin) NHWC fp32 = d/dx; either may be NULL (dx needs x_kind 1).
+ * The workspace holds the fp32 column image (none for 1x1 / stride 1), for dx its gradient, and the GEMM slabs;
+ * backward_dx != 0 sizes it for a call with dx. */
+size_t i2l_conv_f32_workspace_bytes(int x_kind, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                    int pad, int backward_dx);
+int i2l_conv_f32_fwd(const float* x, int x_kind, const float* w, float* z, int B, int H, int W, int Cin, int Cout,
+                     int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, int flags,
+                     i2l_stream_t stream);
+int i2l_conv_f32_bwd(const float* x, int x_kind, const float* w, const float* dz, float* dx, float* dw, int B, int H,
+                     int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace,
+                     size_t workspace_bytes, int flags, i2l_stream_t stream);
+/* nn.BatchNorm2d in training mode on a row-major (M, C) fp32 matrix z, C % 8 == 0 (+ residual add, + ReLU):
+ *   fwd: mean, then the biased variance from a second pass over z - mean (both combined in double); running_* (may both
+ *        be NULL) <- (1 - momentum) * running + momentum * (mean, UNBIASED variance);
+ *        y = act(gamma * (z - mean) * invstd + beta + residual); save_mean / save_invstd (C)
  *   bwd: g = dy masked by y_relu > 0 (y_relu NULL: no ReLU);  dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));
  *        dgamma = sum g * xhat, dbeta = sum g (either may be NULL); dres (may be NULL) = g (or += g): the gradient of
  *        the residual branch. */
 size_t i2l_bn_train_workspace_bytes(int64_t M, int C);
-int i2l_bn_train_fwd_bf16(const void* z, const void* residual, const float* gamma, const float* beta,
-                          float* running_mean, float* running_var, float momentum, float eps, int relu, void* y,
-                          float* save_mean, float* save_invstd, int64_t M, int C, void* workspace,
-                          size_t workspace_bytes, i2l_stream_t stream);
-int i2l_bn_train_bwd_bf16(const float* dy, const void* y_relu, const void* z, const float* gamma, const float* save_mean,
-                          const float* save_invstd, float* dz, float* dgamma, float* dbeta, float* dres,
-                          int dres_accumulate, int64_t M, int C, void* workspace, size_t workspace_bytes,
-                          i2l_stream_t stream);
-/* Convolution gradients as GEMMs: col (B*Ho*Wo, Cin*kh*kw) fp32 with the column order (ci, ky, kx) of the weight
- * tensor, so that i2l_linear_bias_act_bwd(x = col, w = weight viewed (Cout, Cin*kh*kw), dy = dz) yields dw in the
- * weight's own layout and dcol; i2l_col2im_f32 gathers dcol back to dx (B,H,W,Cin) NHWC fp32 (deterministic).
- * x_kind: 0 = NHWC bf16, 1 = NHWC fp32, 2 = NCHW fp32 (the image batch of the stem). */
+int i2l_bn_train_fwd_f32(const float* z, const float* residual, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int relu, float* y,
+                         float* save_mean, float* save_invstd, int64_t M, int C, void* workspace,
+                         size_t workspace_bytes, i2l_stream_t stream);
+int i2l_bn_train_bwd_f32(const float* dy, const float* y_relu, const float* z, const float* gamma, const float* save_mean,
+                         const float* save_invstd, float* dz, float* dgamma, float* dbeta, float* dres,
+                         int dres_accumulate, int64_t M, int C, void* workspace, size_t workspace_bytes,
+                         i2l_stream_t stream);
+/* The two halves of the convolution entry points above, on their own: col (B*Ho*Wo, Cin*kh*kw) fp32 with the column
+ * order (ci, ky, kx) of the weight tensor, and the deterministic gather of a column-image gradient back to
+ * dx (B,H,W,Cin) NHWC fp32.  x_kind: 0 = NHWC bf16, 1 = NHWC fp32, 2 = NCHW fp32. */
 int i2l_im2col_f32(const void* x, int x_kind, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                    float* col, i2l_stream_t stream);
 int i2l_col2im_f32(const float* dcol, int B, int H, int W, int C, int kh, int kw, int stride, int pad, float* dx,
                    int accumulate, i2l_stream_t stream);
-/* nn.MaxPool2d(3, 2, 1) backward (x NHWC bf16 = the forward input, dy / dx fp32 NHWC; the first maximum of a window
- * takes its gradient, as ATen) and nn.AdaptiveAvgPool2d(1) backward (dfeat (B,C) -> dx (B,H,W,C)). */
-int i2l_maxpool3x3s2_bf16_bwd(const void* x, const float* dy, float* dx, int B, int H, int W, int C, i2l_stream_t stream);
+/* nn.MaxPool2d(3, 2, 1) on NHWC fp32 (C % 4 == 0) and its backward (x = the forward input; the first maximum of a
+ * window takes its gradient, as ATen); nn.AdaptiveAvgPool2d(1) + Flatten (B,H,W,C) -> (B,C) and its backward. */
+int i2l_maxpool3x3s2_f32_fwd(const float* x, float* y, int B, int H, int W, int C, i2l_stream_t stream);
+int i2l_maxpool3x3s2_f32_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, i2l_stream_t stream);
+int i2l_global_avgpool_f32_fwd(const float* x, float* y, int B, int H, int W, int C, i2l_stream_t stream);
 int i2l_global_avgpool_bwd_f32(const float* dfeat, float* dx, int B, int H, int W, int C, i2l_stream_t stream);
 
 /* ------------------------------------------------------------------------
@@ -275,14 +308,17 @@ int i2l_greedy_decode(const i2l_decoder_weights* w, const void* workspace, int r
                       i2l_stream_t stream);
 
 /* Same as i2l_greedy_decode with an explicit number of batch rows per workgroup (0 = automatic, else 1, 2
- * or 4; a non-zero value also selects the row-per-workgroup kernel) and flags (I2L_FLAG_AGENT_SCOPE_EXCHANGE).  Rows per workgroup > 1 leaves compute units free for another stream (the weight stream of a
- * workgroup is shared by its rows): GreedyPipeline runs the decode of batch i on half of the chip while the
- * encoder of batch i+1 runs on the other half.  Results do not depend on this parameter. */
+ * or 4; a non-zero value also selects the row-per-workgroup kernel), flags (I2L_FLAG_AGENT_SCOPE_EXCHANGE,
+ * I2L_FLAG_DECODE_GROUP8) and a RESIDENCY SIGNAL: with resident_flag != NULL (a caller-owned device word) the launch
+ * stores resident_value there as soon as its workgroups own their compute units -- a grouped kernel when its last group
+ * has completed the placement exchange, any other kernel at once -- for i2l_stream_wait_value32 on another stream
+ * (GreedyPipeline: the encoder of batch i + 1 starts beside the decode of batch i, never before it).  If a group times
+ * out the word is not written; the waiter's own bound then ends the wait.  Results do not depend on these parameters. */
 int i2l_greedy_decode_ex(const i2l_decoder_weights* w, const void* workspace, int rows, int steps,
                          const int32_t* tok0, const int32_t* forced, const float* h0, const float* c0,
                          float temperature, int select, int stop, int end_id, int rows_per_workgroup,
                          int32_t* ids_out, float* logits_out, float* h_out, float* c_out, int flags,
-                         i2l_stream_t stream);
+                         uint32_t* resident_flag, uint32_t resident_value, i2l_stream_t stream);
 
 /* The sampling branch of Predictor.predict_batch (predictor.py:295-331, taken when temperature > 0 and
  * (top_k > 0 or top_p > 0)): probs = softmax(logits/T); top-k keeps p >= k-th largest; top-p drops a
@@ -352,7 +388,7 @@ int i2l_decoder_train_fwd(const i2l_decoder_weights* w, const float* enc, const 
 int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t* tokens, int B, int T, float dropout_p,
                           uint64_t seed, int attention_path, void* workspace, size_t workspace_bytes,
                           const float* dlogits, const i2l_decoder_grads* grads, float* denc_out,
-                          int flags, i2l_stream_t stream);
+                          int flags, i2l_lanes* lanes, i2l_stream_t stream);
 
 /* nn.CrossEntropyLoss(ignore_index=pad, label_smoothing=eps) over `rows` = B*T rows of logits (rows,V)
  * (trainer.py:111-115,335-336).  loss_sum_and_count_out[0] = SUM over non-pad rows of the per-row loss,

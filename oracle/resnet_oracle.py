@@ -114,3 +114,28 @@ def resnet_encoder_train_step(sd: SD, model_name: str, x: torch.Tensor, dout: to
     out = F.relu(F.linear(feat, sd["encoder.embedding_layer.weight"], sd["encoder.embedding_layer.bias"]))
     (out * dout.to(dtype)).sum().backward()
     return out.detach(), {n: sd[n].grad.detach() for n in trainable}, {k: v.detach() for k, v in new_stats.items()}
+
+
+def resnet_lstm_train_step(sd: SD, model_name: str, cfg: Dict, images: torch.Tensor, formulas: torch.Tensor, state: Dict,
+                           trainable, lr: float = 1e-3, weight_decay: float = 1e-4, clip: float = 5.0, pad_id: int = 0) -> Dict:
+    """One fp32 optimisation step of a resnet_lstm model (trainer.py:303-343, fp32 branch, dropout off): trunk in
+    training mode (batch statistics, running statistics updated in ``sd``), Linear + ReLU (encoder.py:242-247), teacher-
+    forced decoder, label-smoothed CE, clip by the global norm, Adam with coupled L2 over ``trainable`` only (torch's
+    Adam skips parameters without a gradient: frozen ones get no update and no weight decay).  Updates ``sd`` in place."""
+    import img2latex_oracle as O
+    params = {k: (v.detach().clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    new_stats: Dict[str, torch.Tensor] = {}
+    feat = resnet_trunk_train(params, model_name, images, new_stats)
+    enc = F.relu(F.linear(feat, params["encoder.embedding_layer.weight"], params["encoder.embedding_layer.bias"]))
+    logits = O.decoder_forward(params, cfg, enc, formulas[:, :-1])
+    loss = O.ce_label_smooth(logits, formulas[:, 1:], pad_id)
+    names = [k for k in sd if k in trainable]
+    gl = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+    grads = {k: (torch.zeros_like(sd[k]) if g is None else g.detach().clone()) for k, g in zip(names, gl)}
+    raw = {k: g.clone() for k, g in grads.items()}
+    total = O.clip_grad_norm(grads, clip) if clip > 0 else torch.tensor(0.0)
+    with torch.no_grad():
+        O.adam_step({k: sd[k] for k in names}, grads, state, lr, weight_decay)
+        for k, v in new_stats.items():
+            sd[k].copy_(v)
+    return dict(loss=float(loss.detach()), total_norm=float(total), grads=raw)

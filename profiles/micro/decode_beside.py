@@ -57,8 +57,7 @@ def decode_ms(beside=None, reps=6):
                 e1.record(sa)
             if beside is not None:
                 with torch.cuda.stream(sb):
-                    sb.wait_event(e0)
-                    _lib.check(_lib.lib().i2l_stream_spin_us(30.0, _lib.stream_ptr()), "spin")
+                    sb.wait_event(e0)           # (r03 added a 30 us delay kernel here; the pipeline now waits for the residency signal)
                     for _ in range(beside[1]):
                         beside[0]()
         torch.cuda.synchronize()

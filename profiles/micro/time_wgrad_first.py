@@ -15,7 +15,7 @@ dy = torch.randn_like(y); dw = torch.empty_like(w); db = torch.empty_like(b)
 nb2 = L.i2l_conv_bwd_workspace_bytes(B, Cin, H, W, Cout); ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
 for fl, name in ((0, "sparse kernel"), (_lib.FLAG_CONV_NO_SPARSE_WGRAD, "implicit-im2col GEMM")):
     def run():
-        assert L.i2l_conv3x3_relu_pool2_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), am.data_ptr(), dy.data_ptr(), None, dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout, ws2.data_ptr(), nb2, fl, _lib.stream_ptr()) == 0
+        assert L.i2l_conv3x3_relu_pool2_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), am.data_ptr(), dy.data_ptr(), None, dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout, ws2.data_ptr(), nb2, fl, None, _lib.stream_ptr()) == 0
     for _ in range(5): run()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): run()

@@ -11,8 +11,8 @@ model = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), s
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=42, out_scale=8.0, enc_scale=16.0).items()})
 model = model.to(dev).eval()
 x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(dev)
-for stag in (None, 0.0):
-    pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8, decode_priority=-1, stagger_us=stag)
+for stag in (None, False):
+    pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8, decode_priority=-1, hold_encoder=stag)
     seen = []
     for i in range(40):
         if pipe.pending() >= pipe.depth:
@@ -22,4 +22,4 @@ for stag in (None, 0.0):
     while pipe.pending():
         pipe.collect()
     torch.cuda.synchronize()
-    print("stagger", stag, "last:", model.decoder.group_status(), "one-XCD counts seen:", sorted(set(s["groups_on_one_xcd"] for s in seen if s)))
+    print("hold_encoder", stag, "last:", model.decoder.group_status(), "one-XCD counts seen:", sorted(set(s["groups_on_one_xcd"] for s in seen if s)))

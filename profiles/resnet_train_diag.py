@@ -1,4 +1,4 @@
-"""Where do the HIP training forward and the bf16-emulating oracle part ways?  Per unit: max |diff| / max |ref| of the
+"""Where do the HIP training forward and the fp32 oracle part ways (r03: the bf16-emulating oracle)?  Per unit: max |diff| / max |ref| of the
 activation, the smallest per-channel std / |mean| of the raw conv output (a channel whose spread is below bf16's
 resolution of its mean is normalised to rounding noise)."""
 import os, sys
@@ -20,7 +20,7 @@ sd = {"encoder." + k: torch.from_numpy(v.copy()) for k, v in np_sd.items()}
 x = torch.from_numpy(synth.uniform(5, "images", (B, 3, H, W), -1.0, 1.0))
 out, tape = encoder_train_forward(enc, x.cuda())
 taps = {}
-RO.resnet_trunk_train(sd, name, x, {}, emulate_bf16=True, taps=taps)
+RO.resnet_trunk_train(sd, name, x, {}, emulate_bf16=False, taps=taps)
 names = {id(m): n for n, m in enc.named_modules()}
 for u in tape["units"]:
     key = "encoder." + names[id(u["conv"])]

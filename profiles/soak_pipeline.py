@@ -1,4 +1,4 @@
-"""Soak of GreedyPipeline as bench.py uses it (r03 HEAD: stagger behind the decode launch, decoder prepare on the encoder stream
+"""Soak of GreedyPipeline as bench.py uses it (r04: encoder held behind the decode's residency signal, decoder prepare on the encoder stream
 into rotating workspaces): thousands of batches from three alternating image sets, EVERY result compared with the
 one-batch-at-a-time search of the same kernel; throughput of the run."""
 import os, sys, time

@@ -50,6 +50,40 @@ def test_library_has_no_global_switches():
     assert L.i2l_conv_bf16_workspace_bytes(2, 64, 320, 3, 64, 7, 7, 2, 3, _lib.FLAG_RESNET_IM2COL_STEM) > 2 * 32 * 160 * 147 * 2
 
 
+def test_library_has_no_file_scope_mutable_state():
+    """caller-owned resources, explicit stream, no global state.  r03 kept a per-device table of side
+    streams behind a mutex; they live in caller-owned i2l_lanes objects now.  Every data / bss
+    symbol of the library must be a kernel handle of the HIP fat binary (demangles like a function), a FUNCTION-LOCAL
+    static (`f(...)::name`: the per-device "attribute already set" bit masks, an idempotent cache) or toolchain furniture."""
+    import re
+    import subprocess
+    out = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    toolchain = ("DW.ref.", "_DYNAMIC", "_GLOBAL_OFFSET_TABLE_", "__hip_", "__do_", "completed.", "__dso_handle", "__TMC_END__",
+                 "typeinfo for", "vtable for", "typeinfo name for", "guard variable for", "__bss_start", "_edata", "_end",
+                 "__frame_dummy", "__JCR", "__CTOR", "__DTOR", "__init_array", "__fini_array", "_fini", "_init", "__data_start",
+                 "data_start", "__gmon_start__", "__EH_FRAME", "__GNU_EH", "__FRAME_END__", "__cuda", "__hipRegister",
+                 "__dummy", "__abi_tag", "__fini", "__init")
+    offenders, locals_ = [], []
+    for line in out.splitlines():
+        parts = line.split(None, 2)
+        if len(parts) < 3 or parts[1] not in "bBdD":
+            continue
+        name = parts[2]
+        if name.startswith(toolchain):
+            continue
+        if re.search(r"\)(?: const)?::[A-Za-z_]\w*$", name) or re.match(r"i2l_\w+::[A-Za-z_]\w*$", name):
+            locals_.append(name)           # f(...)::x, or extern "C" i2l_f::x
+            continue
+        if name.endswith(")"):             # a __global__ function's host-side handle
+            continue
+        offenders.append(name)
+    assert not offenders, offenders
+    # the function-local statics are the attribute caches and nothing else
+    assert all(n.rsplit("::", 1)[1].startswith(("attr", "attr_done", "attr8")) for n in locals_), locals_
+    src = open(os.path.join(REPO, "hmer-img2latex_amd", "csrc", "api.hip")).read()
+    assert "std::mutex" not in src and "g_side" not in src
+
+
 def test_state_dict_keys_match_reference():
     cfg = synth.model_config(lstm_layers=2, attention=True, embedding_dim=32, hidden_dim=64, vocab_size=50,
                              channels=1, img_height=16, img_width=32, conv_filters=(4, 8, 16))

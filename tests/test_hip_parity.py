@@ -1095,6 +1095,101 @@ def test_pipeline_with_two_encoder_streams_resnet():
         assert np.array_equal(g, want[i]), i
 
 
+def test_pipeline_with_two_encoder_streams_cnn():
+    """GreedyPipeline(encoder_streams=2) over the CNN encoder: two forwards of ONE CNNEncoder run side by
+    side, so its FC split-K slabs and packed filter images must be per stream.  Eight batches of three distinct image sets:
+    every batch's ids equal the one-batch-at-a-time search on the same decode kernel, in submission order."""
+    from img2latex_amd.pipeline import GreedyPipeline
+    d, cfg, sd_kw = load("primary_cfg2")
+    m, _ = model_for("primary_cfg2", sd_kw, cfg)
+    sets = [torch.from_numpy(synth.make_images(256, cfg, seed=s)).to(DEV) for s in (1234, 77, 78)]
+    with torch.no_grad():
+        want = [_lib.check_ids(m.greedy_ids(m.encoder(x), START, END, 60, flags=_lib.FLAG_DECODE_GROUP8)[0].cpu()).numpy()
+                for x in sets]
+    assert not np.array_equal(want[0], want[1])
+    pipe = GreedyPipeline(m, START, END, 60, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8, encoder_streams=2)
+    order = [0, 1, 2, 2, 0, 1, 0, 2]
+    got = []
+    for i in order:
+        if pipe.pending() >= pipe.depth:
+            got.append(pipe.collect().numpy().copy())
+        pipe.submit(sets[i])
+    while pipe.pending():
+        got.append(pipe.collect().numpy().copy())
+    assert len(got) == len(order)
+    for i, g in zip(order, got):
+        assert np.array_equal(g, want[i]), i
+    assert len({k[1] for k in m.encoder._packed_ws}) >= 2               # one packed image per (block, stream)
+    n_slots = len([k for k in m.decoder._ws_by_stream if isinstance(k, tuple) and k[0] == "slot"])
+    assert n_slots >= 1
+    pipe.close()                                                        # the pipeline's decoder workspaces go back
+    assert not [k for k in m.decoder._ws_by_stream if isinstance(k, tuple) and k[0] == "slot"]
+
+
+def test_residency_signal_and_bounded_stream_wait():
+    """i2l_greedy_decode_ex's residency signal + i2l_stream_wait_value32 (r04: GreedyPipeline's dependency between decode(i)
+    and encoder(i + 1), where r03 had a 30 us delay kernel), through the C ABI:
+    the grouped kernels (4 and 8 members) publish the value once their groups are resident, an ungrouped launch publishes at
+    once, a launch with a silent member (forced time-out) never does; a wait on a published value returns at once, a wait
+    on a value that never comes returns after its bound; and in a traced pipeline every encoder starts after the decode
+    launch it was held for, with identical ids."""
+    import ctypes
+    import time
+    from img2latex_amd.pipeline import GreedyPipeline
+    d, cfg, sd_kw = load("primary_cfg2_clock")
+    m, _ = model_for("primary_cfg2_clock", sd_kw, cfg)
+    L = _lib.lib()
+    x = torch.from_numpy(synth.make_images(64, cfg, seed=1234)).to(DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        enc = m.encoder(x)
+        base = m.greedy_ids(enc, START, END, 40)[0].cpu()
+        for n, (fl, rows_per_wg) in enumerate([(0, 0), (_lib.FLAG_DECODE_GROUP8, 0), (0, 1)], start=1):
+            ids, _, _ = m.decoder.run_steps(enc, 40, torch.full((64,), START, dtype=torch.int32, device=DEV), flags=fl,
+                                            rows_per_workgroup=rows_per_wg, resident=(flag, 100 + n))
+            torch.cuda.synchronize()
+            assert int(flag.item()) == 100 + n, (fl, rows_per_wg)
+            assert int((ids.cpu() != base).any(dim=1).sum()) <= 2           # the signal does not touch the results
+        bad = _lib.FLAG_DECODE_GROUP8 | _lib.FLAG_TEST_DROP_MEMBER | _lib.FLAG_TEST_SHORT_TIMEOUT
+        ids, _, _ = m.decoder.run_steps(enc, 40, torch.full((64,), START, dtype=torch.int32, device=DEV), flags=bad,
+                                        resident=(flag, 999))
+        torch.cuda.synchronize()
+        assert bool((ids == -3).all()) and int(flag.item()) == 103           # a group that never assembled says nothing
+    # the wait: satisfied (wrapping compare: 103 - 50 >= 0), then a value that never comes
+    s = torch.cuda.Stream()
+    assert L.i2l_stream_wait_value32(flag.data_ptr(), 50, 5000.0, s.cuda_stream) == 0
+    s.synchronize()
+    t0 = time.perf_counter()
+    assert L.i2l_stream_wait_value32(flag.data_ptr(), 104, 3000.0, s.cuda_stream) == 0
+    s.synchronize()
+    waited = time.perf_counter() - t0
+    assert 2.5e-3 <= waited <= 0.5, waited
+    assert L.i2l_stream_wait_value32(None, 1, 10.0, s.cuda_stream) == -1 and \
+        L.i2l_stream_wait_value32(flag.data_ptr(), 1, 1e9, s.cuda_stream) == -1
+    # the pipeline holds every encoder behind the decode launch it depends on
+    x256 = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(DEV)
+    for hold in (True, False):
+        pipe = GreedyPipeline(m, START, END, 150, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8, decode_priority=-1,
+                              hold_encoder=hold)
+        pipe.trace = []
+        outs = []
+        for _ in range(12):
+            if pipe.pending() >= pipe.depth:
+                outs.append(pipe.collect().clone())
+            pipe.submit(x256)
+        while pipe.pending():
+            outs.append(pipe.collect().clone())
+        tr = pipe.trace
+        offs = [a["dec_start"].elapsed_time(b["enc_start"]) for a, b in zip(tr[:-1], tr[1:])]
+        record(f"pipeline hold_encoder={hold}: fraction of encoders that started after the previous decode's launch",
+               float(np.mean([o > 0 for o in offs])))
+        if hold:
+            assert all(o > 0 for o in offs), offs
+            assert int(pipe._resident.item()) == 12
+        assert all(torch.equal(o, outs[0]) for o in outs)
+        pipe.close()
+
+
 def test_pipeline_falls_back_when_the_grouped_decode_times_out():
     """A batch whose grouped decode timed out (forced: silent member + 2 ms limits) is decoded again on the
     row-per-workgroup kernel inside GreedyPipeline.collect(): same ids as the healthy pipeline, one warning per batch."""

@@ -253,7 +253,7 @@ def test_conv_bwd_odd_shapes():
         ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
         assert L.i2l_conv3x3_relu_pool2_bwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), am.data_ptr(), dyd.data_ptr(),
                                             dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout,
-                                            ws2.data_ptr(), nb2, 0, _lib.stream_ptr()) == 0
+                                            ws2.data_ptr(), nb2, 0, None, _lib.stream_ptr()) == 0
         rel_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, "dx")
         rel_close(dw.cpu().numpy(), w.grad.numpy(), 2e-4, "dw")
         rel_close(db.cpu().numpy(), b.grad.numpy(), 2e-4, "db")
@@ -295,7 +295,7 @@ def test_first_block_sparse_weight_gradient():
             ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
             assert L.i2l_conv3x3_relu_pool2_bwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), am.data_ptr(), dyd.data_ptr(),
                                                 None, dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout,
-                                                ws2.data_ptr(), nb2, fl, _lib.stream_ptr()) == 0
+                                                ws2.data_ptr(), nb2, fl, None, _lib.stream_ptr()) == 0
             outs.append((dw.cpu().numpy(), db.cpu().numpy()))
         tag = f"first-block wgrad {B}x{Cin}x{H}x{W}->{Cout}"
         rel_close(outs[0][0], w.grad.numpy(), 2e-5, tag + " dw (sparse kernel vs float64)")
@@ -406,7 +406,7 @@ def test_train_step_loss_decreases_and_dropout_runs():
 
 
 def test_side_stream_weight_gradients_are_the_same_numbers():
-    """I2L_FLAG_SIDE_WGRAD moves the weight-gradient kernels to the library's side stream: same kernels, same sums, so every
+    """Side lanes (i2l_lanes, owned by TrainStep) move the weight-gradient kernels off the main stream: same kernels, same sums, so every
     gradient is bit-identical with and without it (primary dims, 64 x 21) -- except the embedding rows, whose scatter adds
     with atomics in an order that varies from launch to launch on ONE stream as well (compared to 1e-6 of the largest)."""
     from img2latex_amd.training import TrainStep
@@ -434,10 +434,19 @@ def test_side_stream_weight_gradients_are_the_same_numbers():
 
 
 def test_side_wgrad_flag_through_the_c_abi():
-    """I2L_FLAG_SIDE_WGRAD + i2l_side_stream_join called the way a C host would: conv block backward (with data gradient:
-    lane 1) and linear backward (lane 0) with the flag, one join, then every output equals the one-stream call bit for bit."""
+    """i2l_lanes_create / _join / _destroy called the way a C host would: two caller-made streams, conv block backward (with
+    data gradient: lane 1) and linear backward (lane 0) with the lanes object, one join, then every output equals the
+    one-stream call (lanes == NULL) bit for bit.  Argument errors come back as codes."""
+    import ctypes
     torch.manual_seed(9)
     L = _lib.lib()
+    side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    arr = (ctypes.c_void_p * 2)(*[s.cuda_stream for s in side_streams])
+    handle = ctypes.c_void_p()
+    assert L.i2l_lanes_create(arr, 2, ctypes.byref(handle)) == 0 and handle.value
+    assert L.i2l_lanes_create(arr, 0, ctypes.byref(handle)) == -1 and L.i2l_lanes_create(arr, 5, ctypes.byref(handle)) == -1
+    assert L.i2l_lanes_create((ctypes.c_void_p * 1)(None), 1, ctypes.byref(ctypes.c_void_p())) == -1     # the default stream
+    assert L.i2l_lanes_join(None, _lib.stream_ptr()) == -1 and L.i2l_lanes_destroy(None) == 0
     B, Cin, H, W, Cout = 8, 32, 16, 80, 64
     x = torch.randn(B, Cin, H, W, device=DEV)
     w = torch.randn(Cout, Cin, 3, 3, device=DEV) / 17.0
@@ -454,22 +463,24 @@ def test_side_wgrad_flag_through_the_c_abi():
     fy = torch.relu(fx @ fw.t())
     fdy = torch.randn(M, N, device=DEV)
     outs = []
-    for fl in (0, _lib.FLAG_SIDE_WGRAD):
+    for fl in (None, handle.value):
         dx, dw, db = torch.empty_like(x), torch.full_like(w, float("nan")), torch.full_like(b, float("nan"))
         nb2 = L.i2l_conv_bwd_workspace_bytes(B, Cin, H, W, Cout)
         ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
         assert L.i2l_conv3x3_relu_pool2_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), am.data_ptr(), dy.data_ptr(),
                                             dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cin, H, W, Cout,
-                                            ws2.data_ptr(), nb2, fl, _lib.stream_ptr()) == 0
+                                            ws2.data_ptr(), nb2, 0, fl, _lib.stream_ptr()) == 0
         fdx, fdw, fdb = torch.empty_like(fx), torch.full_like(fw, float("nan")), torch.full((N,), float("nan"), device=DEV)
         nb3 = L.i2l_linear_bwd_workspace_bytes(M, K, N)
         ws3 = torch.empty(nb3, dtype=torch.uint8, device=DEV)
         assert L.i2l_linear_bias_act_bwd(fx.data_ptr(), fw.data_ptr(), fy.data_ptr(), fdy.data_ptr(), fdx.data_ptr(),
-                                         fdw.data_ptr(), fdb.data_ptr(), M, K, N, 1, ws3.data_ptr(), nb3, fl,
+                                         fdw.data_ptr(), fdb.data_ptr(), M, K, N, 1, ws3.data_ptr(), nb3, 0, fl,
                                          _lib.stream_ptr()) == 0
-        assert L.i2l_side_stream_join(_lib.stream_ptr()) == 0          # a no-op for the one-stream call
+        if fl:
+            assert L.i2l_lanes_join(fl, _lib.stream_ptr()) == 0
         torch.cuda.synchronize()
         outs.append([t.clone() for t in (dx, dw, db, fdx, fdw, fdb)])
+    assert L.i2l_lanes_destroy(handle.value) == 0
     for a, c in zip(outs[0], outs[1]):
         assert not torch.isnan(c).any()
         assert torch.equal(a, c)

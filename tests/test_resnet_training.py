@@ -4,9 +4,9 @@ gradients; the shipped config trains everything, configs/config.yaml:43), the tr
 csrc/resnet_train.hip, through torch.autograd (the reference Trainer's loss.backward()) and through TrainStep.
 
 Parity stays UNPINNED against the reference itself (torchvision absent, remote weights: SURVEY 8c).  The yardstick is
-oracle/resnet_oracle.py's autograd restatement, evaluated twice: with bf16 rounding emulated at the points where the
-HIP path stores bf16 (isolates kernel defects from the precision of the bf16 data path) and in plain fp32 (what the
-reference's modules compute; the distance is dominated by bf16 activations and recorded)."""
+oracle/resnet_oracle.py's autograd restatement in plain fp32 -- what the reference's modules compute in the Trainer's
+fp32 branch.  Since r04 the HIP training path is fp32 grade too (fp32 activations, split-bf16 matrix-core GEMMs), so
+the end-to-end comparison is a real assertion: r03's bf16 tape could only be held to "median cosine >= 0.3"."""
 import numpy as np
 import pytest
 import torch
@@ -39,13 +39,13 @@ def _bf(t):
 
 def _unit_reference(u, dy=None):
     """One conv + BatchNorm(train) (+ residual) (+ ReLU) unit in fp32 torch ON THE DEVICE (rocBLAS / MIOpen, none of
-    this repo's kernels), fed the operands the HIP unit saw (bf16-rounded input and filter).  With dy: also the
-    gradients of sum(y * dy) with respect to input, filter, gamma, beta and the residual."""
+    this repo's kernels), fed the operands the HIP unit saw.  With dy: also the gradients of sum(y * dy) with respect
+    to input, filter, gamma, beta and the residual."""
     conv, bn = u["conv"], u["bn"]
     x = u["x"].detach()
-    x = _bf(x) if u["nchw"] else x.float().permute(0, 3, 1, 2)
+    x = x if u["nchw"] else x.permute(0, 3, 1, 2)
     x = x.contiguous().requires_grad_(dy is not None)
-    w = _bf(conv.weight.detach()).requires_grad_(dy is not None)
+    w = conv.weight.detach().clone().requires_grad_(dy is not None)
     gamma, beta = (t.detach().clone().requires_grad_(dy is not None) for t in (bn.weight, bn.bias))
     res = None
     if u["residual"] is not None:
@@ -54,7 +54,7 @@ def _unit_reference(u, dy=None):
     yn = torch.nn.functional.batch_norm(z, None, None, gamma, beta, training=True, eps=bn.eps)
     y = yn if res is None else yn + res
     if u["relu"] and dy is not None:
-        # the ReLU gate is a discrete decision: an activation within bf16 rounding of zero may fall either way, and a
+        # the ReLU gate is a discrete decision: an activation within fp32 rounding of zero may fall either way, and a
         # flipped gate moves that element's gradient by 100 % -- the gradients are judged UNDER THE HIP FORWARD'S GATES
         # (like the conv blocks' pooling decisions in test_hip_training.py); the forward check above bounds the values
         y = y * (u["y"].float() > 0).permute(0, 3, 1, 2)
@@ -73,8 +73,9 @@ def _rel(a, b):
     return float((a.float() - b.float()).abs().max()) / (float(b.float().abs().max()) + 1e-20)
 
 
-@pytest.mark.parametrize("name,freeze,B,H,W", [("resnet50", True, 4, 64, 320), ("resnet18", False, 3, 32, 96),
-                                               ("resnet50", False, 3, 64, 128)])
+@pytest.mark.parametrize("name,freeze,B,H,W", [("resnet50", True, 4, 64, 320), ("resnet50", False, 4, 64, 320),
+                                               ("resnet50", True, 32, 64, 320), ("resnet50", False, 32, 64, 320),
+                                               ("resnet18", False, 3, 32, 96)])
 def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
@@ -92,35 +93,32 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
     enc.trace_bwd = []
     encoder_train_backward(enc, tape, dout.to(DEV), grads)
     bwd, enc.trace_bwd = enc.trace_bwd, None
+    tag = f"{name} freeze={freeze} B={B} {H}x{W}"
     # ---- (1) every unit of the forward against an independent fp32 computation on the same operands
     worst = dict(z=0.0, y=0.0, stat=0.0, run=0.0)
     for u in tape["units"]:
+        assert u["z"].dtype == torch.float32 and u["y"].dtype == torch.float32       # the tape is fp32 (r04)
         ref = _unit_reference(u)
-        zf, yf = u["z"].float(), u["y"].float()
-        # z and y are stored in bf16: one ulp (2^-8 of the value) plus fp32 summation noise
-        assert float(((zf - ref["z"]).abs() - 2.0 ** -7 * ref["z"].abs()).max()) <= 2e-3 * max(1.0, float(ref["z"].abs().max()))
+        zf, yf = u["z"], u["y"]
         worst["z"] = max(worst["z"], _rel(zf, ref["z"]))
-        worst["stat"] = max(worst["stat"], _rel(u["mean"], zf.mean(dim=(0, 1, 2))),
-                            _rel(1.0 / u["invstd"] ** 2 - u["bn"].eps, zf.var(dim=(0, 1, 2), unbiased=False)))
-        # y from the HIP z / statistics themselves (the statistics of a bf16-rounded z differ slightly from the fp32 z's)
+        worst["stat"] = max(worst["stat"], _rel(u["mean"], zf.double().mean(dim=(0, 1, 2))),
+                            _rel(1.0 / u["invstd"].double() ** 2 - u["bn"].eps, zf.double().var(dim=(0, 1, 2), unbiased=False)))
+        # y from the HIP z / statistics themselves: the elementwise formula, evaluated in another order
         yn = (zf - u["mean"]) * u["invstd"] * u["bn"].weight.detach() + u["bn"].bias.detach()
-        mag = yn.abs() + (u["residual"].float().abs() if u["residual"] is not None else 0.0)   # one bf16 ulp of either term
-        yn = _bf(yn) + (u["residual"].float() if u["residual"] is not None else 0.0)
+        yn = yn + (u["residual"] if u["residual"] is not None else 0.0)
         yn = torch.relu(yn) if u["relu"] else yn
-        # two bf16 roundings (the normalised value, then the sum), the first of which may fall on the neighbouring bf16
-        # when the fp32 expression is evaluated in another order: <= 1.5 ulp(norm) + 0.5 ulp(y), ulp(v) <= 2^-7 |v|
-        assert float(((yf - yn).abs() - 2.0 ** -6 * mag).max()) <= 1e-5 * max(1.0, float(yn.abs().max()))
+        assert float((yf - yn).abs().max()) <= 1e-5 * max(1.0, float(yn.abs().max()))
         worst["y"] = max(worst["y"], _rel(yf, ref["y"]))
         key = next(n for n, mod in enc.named_modules() if mod is u["bn"])
         M = zf.numel() // zf.shape[-1]
-        rm = 0.9 * old_stats[key + ".running_mean"] + 0.1 * zf.mean(dim=(0, 1, 2))
-        rv = 0.9 * old_stats[key + ".running_var"] + 0.1 * zf.var(dim=(0, 1, 2), unbiased=M > 1)
+        rm = 0.9 * old_stats[key + ".running_mean"].double() + 0.1 * zf.double().mean(dim=(0, 1, 2))
+        rv = 0.9 * old_stats[key + ".running_var"].double() + 0.1 * zf.double().var(dim=(0, 1, 2), unbiased=M > 1)
         worst["run"] = max(worst["run"], _rel(u["bn"].running_mean, rm), _rel(u["bn"].running_var, rv))
         assert int(u["bn"].num_batches_tracked) == 1
-    assert worst["stat"] <= 1e-4 and worst["run"] <= 1e-4, worst
-    assert worst["z"] <= 1.5e-2 and worst["y"] <= 5e-2, worst
     for k, v in worst.items():
-        record(f"{name} B={B} {H}x{W} train forward, worst unit: {k} vs independent fp32 [rel to max]", v)
+        record(f"{tag} train forward, worst unit: {k} vs independent fp32 [rel to max]", v)
+    assert worst["stat"] <= 2e-6 and worst["run"] <= 2e-6, worst          # r03 (statistics of a bf16 z): 1e-4
+    assert worst["z"] <= 2e-5 and worst["y"] <= 1e-4, worst               # r03 (bf16 tape): 1.5e-2 / 5e-2
     # ---- (2) every unit of the backward: gradients of the SAME upstream gradient through an fp32 autograd of the unit
     first_trainable = min(i for i, u in enumerate(tape["units"])
                           if any(p.requires_grad for p in list(u["conv"].parameters()) + list(u["bn"].parameters())))
@@ -138,9 +136,8 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
         if rec["dres"] is not None and ref["dres"] is not None:
             wb["dres"] = max(wb["dres"], _rel(rec["dres"], ref["dres"]))
     for k, v in wb.items():
-        record(f"{name} freeze={freeze} train backward, worst unit: {k} vs fp32 autograd of the unit [rel to max]", v)
-    # the HIP backward reads the bf16-rounded z and y (ReLU mask, xhat): a few 1e-3 of the maximum per unit
-    assert max(wb.values()) <= 3e-2, wb
+        record(f"{tag} train backward, worst unit: {k} vs fp32 autograd of the unit [rel to max]", v)
+    assert max(wb.values()) <= 1e-3, wb                                   # r03 (bf16 z / y on the tape): 3e-2
     # ---- (2b) the ROUTING between the units, exactly: every unit's upstream gradient is the sum of what its consumers
     #           produced (main path, residual branch / downsample), the head of the chain is the average-pool backward of
     #           d(features), the stem's is the max-pool backward (checked against torch's on the same input)
@@ -172,26 +169,25 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
         pin = tape["pool_in"].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
         torch.nn.functional.max_pool2d(pin, 3, stride=2, padding=1).backward(dh0.permute(0, 3, 1, 2).contiguous())
         assert torch.equal(r0["dy"], pin.grad.permute(0, 2, 3, 1).contiguous())
-    # ---- (3) end to end against the oracle (trainer's view): bf16 differences compound through up to 53 BatchNorms
-    #          with batch statistics of as few as 6 samples per channel, so only direction and scale are asserted
-    want_out, want_g, want_stats = RO.resnet_encoder_train_step(sd, name, x, dout, trainable, emulate_bf16=True)
+    # ---- (3) end to end against the fp32 oracle (the Trainer's view).  The random-weight trunk amplifies a relative
+    #          perturbation ~100x over its 53 units (profiles/micro/resnet_precision_cpu.py: the fp32 oracle itself sits
+    #          at cosine 0.9991 - 0.9998 from its own float64 evaluation), so the bound is a cosine, for EVERY parameter
+    want_out, want_g, want_stats = RO.resnet_encoder_train_step(sd, name, x, dout, trainable, emulate_bf16=False)
     e_out = float((out.detach().cpu() - want_out).abs().max()) / max(1.0, float(want_out.abs().max()))
-    record(f"{name} train fwd B={B} {H}x{W} output vs bf16-emulating oracle, end to end [rel to max(1,|ref|)]", e_out)
-    cosines = []
+    record(f"{tag} train fwd output vs fp32 oracle, end to end [rel to max(1,|ref|)]", e_out)
+    cosines = {}
     for n, p in enc.named_parameters():
         if p.requires_grad:
             assert torch.isfinite(grads[n]).all(), n
-            cosines.append(_cos(grads[n].cpu(), want_g["encoder." + n]))
-    cosines = np.sort(np.array(cosines))
-    record(f"{name} freeze={freeze} gradients end to end: 1 - lowest cosine vs bf16-emulating oracle", 1.0 - cosines[0])
-    record(f"{name} freeze={freeze} gradients end to end: 1 - median cosine vs bf16-emulating oracle", 1.0 - float(np.median(cosines)))
-    # End to end the two bf16 data paths drift apart by ~7 % per unit (profiles/r03/resnet_train_diag.txt: steady growth
-    # from 3e-3 at the stem to 0.3 at layer4, no jump at any layer): random weights, BatchNorm re-normalising every
-    # layer with batch statistics over as few as 24 positions and the ReLU gates make the net amplify rounding noise, and
-    # two roundings of the same z (fp32 sums in another order) are two different noises.  So end to end only sanity is
-    # asserted -- finite, same direction for the bulk of the parameters -- and the unit-level checks (1), (2) and the
-    # exact routing check (2b) above carry the correctness claim.
-    assert np.isfinite(e_out) and float(np.median(cosines)) >= 0.3, (e_out, cosines[:5], float(np.median(cosines)))
+            cosines[n] = _cos(grads[n].cpu(), want_g["encoder." + n])
+    cs = np.sort(np.array(list(cosines.values())))
+    record(f"{tag} gradients end to end: 1 - lowest cosine vs fp32 oracle", 1.0 - cs[0])
+    record(f"{tag} gradients end to end: 1 - median cosine vs fp32 oracle", 1.0 - float(np.median(cs)))
+    e_stat = max(_rel(enc.state_dict()[k[len("encoder."):]].cpu(), v) for k, v in want_stats.items())
+    record(f"{tag} running statistics after the step vs fp32 oracle [rel to max]", e_stat)
+    assert e_out <= 3e-2, e_out
+    assert cs[0] >= 0.99, sorted(cosines.items(), key=lambda kv: kv[1])[:5]
+    assert e_stat <= 1e-2, e_stat
     # ---- (4) the torch.autograd route (the reference Trainer's loss.backward()) gives the same gradients; frozen
     #          parameters get none
     enc2, _ = _encoder(name, H, W, freeze, seed=11)
@@ -261,3 +257,43 @@ def test_resnet_lstm_train_step():
         if p.requires_grad:
             g2 = tsb.grad_views[n] / count
             assert float((p.grad - g2).abs().max()) <= 1e-5 * max(1.0, float(g2.abs().max())), n
+
+
+def test_resnet50_lstm_30_step_loss_curve_vs_fp32_oracle():
+    """30 optimisation steps of an UNFROZEN resnet50_lstm (the shipped configuration trains the trunk,
+    configs/config.yaml:43) through TrainStep against the oracle's fp32 steps (trainer.py:303-343 restated:
+    oracle/resnet_oracle.py::resnet_lstm_train_step) on the same synthetic batches: every loss within 2 % (two correct
+    evaluations -- the oracle in float32 and in float64 -- are themselves up to 1.2 % apart by step 17)."""
+    from img2latex_amd.training import TrainStep
+    cfg = synth.model_config(vocab_size=60, embedding_dim=64, hidden_dim=64, dropout=0.0)
+    enc_p = dict(img_height=64, img_width=320, channels=3, model_name="resnet50", embedding_dim=64, freeze_backbone=False)
+    m = Seq2SeqModel("resnet_lstm", 60, enc_p, synth.decoder_params(cfg))
+    shapes = [(k, tuple(v.shape)) for k, v in m.encoder.state_dict().items()]
+    full = {"encoder." + k: torch.from_numpy(v) for k, v in synth.make_resnet_state_dict(shapes, seed=3).items()}
+    full.update({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=4).items() if k.startswith("decoder.")})
+    m.load_state_dict(full)
+    m = m.to(DEV)
+    sd = {k: v.clone() for k, v in full.items()}
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    B, steps = 8, 30
+    batches = [(torch.from_numpy(synth.uniform(20 + i, "images", (B, 3, 64, 320), -1.0, 1.0)),
+                torch.from_numpy(synth.make_formulas(B, 14, 60, seed=30 + i, min_len=5))) for i in range(4)]
+    ts = TrainStep(m, lr=1e-3)
+    state = {}
+    got, want = [], []
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    for i in range(steps):
+        x, f = batches[i % len(batches)]
+        got.append(float(ts.step(x.to(DEV), f.to(DEV))["loss"]))
+        want.append(RO.resnet_lstm_train_step(sd, "resnet50", cfg, x, f, state, trainable, lr=1e-3)["loss"])
+    got, want = np.array(got), np.array(want)
+    rel = np.abs(got - want) / want
+    record("resnet50_lstm unfrozen, 30 TrainStep losses vs fp32 oracle steps: worst relative difference", float(rel.max()))
+    record("resnet50_lstm unfrozen, 30 TrainStep losses: first / last", float(got[0]))
+    assert np.isfinite(got).all() and got[-1] < got[0], got
+    assert rel.max() <= 2e-2, (got, want)
+    # The running statistics of the two runs are recorded, not asserted: 30 Adam steps through this trunk are chaotic --
+    # the oracle's OWN float32 and float64 trajectories end 0.99 of the maximum apart, with losses up to 1.2 % apart
+    # (profiles/micro/resnet_chaos_cpu.py); the one-step check above holds them to 1e-2.
+    rs = max(_rel(m.state_dict()[k].cpu(), sd[k]) for k in sd if "running" in k)
+    record("resnet50_lstm unfrozen, running statistics after 30 steps vs fp32 oracle [rel to max; fp32 vs fp64 oracle: 0.99]", rs)
