@@ -189,6 +189,11 @@ def test_bench_self_launches_n_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 3 and out["ranks_seen"] == 6.0          # ranks 0, 1, 2 all took part
+    # the driver's largest case, through the train mode's argument path: 8 ranks rendezvous and all take part
+    r = _run_bench(["--gpus", "8", "--mode", "train", "--launch-probe"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 36.0
 
 
 def test_bench_refuses_a_mismatched_world():

@@ -126,6 +126,70 @@ def test_two_piece_allreduce_is_bit_identical_to_one():
     assert out["two_piece_equals_single"] and out["finish_only_equals_single"]
 
 
+def _step_worker(rank, world, port, out, overlap):
+    """One full optimisation step the way TrainStep does it under data parallelism, on the CPU oracle's arithmetic: shard ->
+    SUM-loss gradients into one flat buffer [grads..., loss_sum, count] -> the product's all-reduce (one call, or
+    dp.OverlappedAllReduce's two pieces) -> division by the GLOBAL count -> clip by the GLOBAL norm -> Adam."""
+    from img2latex_amd.training.dp import OverlappedAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = synth.model_config(**CFG)
+    sd = O.to_torch_sd(synth.make_state_dict(cfg, seed=3))
+    n_rows = 509                                                    # 8 x 63 + 5: ragged shards (64 x 5, 63 x 3)
+    x = torch.from_numpy(synth.make_images(n_rows, cfg, seed=1234))
+    forms = torch.from_numpy(synth.make_formulas(n_rows, T, cfg["vocab_size"], seed=777, min_len=4))
+    lo, hi = shard_batch(n_rows, rank, world)
+    flat = _sum_loss_grads(sd, cfg, x[lo:hi], forms[lo:hi])
+    if overlap:                     # two pieces, as TrainStep issues them (its split sits in front of the conv gradients;
+        r = OverlappedAllReduce(flat, (2 * flat.numel()) // 3)      # element-wise sums do not care where)
+        r.start_early()
+        r.finish()
+    else:
+        all_reduce_gradients(flat)
+    count = flat[-1]
+    grads, off = {}, 0
+    for k, v in sd.items():
+        grads[k] = (flat[off:off + v.numel()] / count).view_as(v).clone()
+        off += v.numel()
+    total = O.clip_grad_norm(grads, 5.0)
+    state = {}
+    with torch.no_grad():
+        O.adam_step(sd, grads, state)
+    mine = torch.cat([v.reshape(-1) for v in sd.values()])
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    if rank == 0:
+        ref = O.to_torch_sd(synth.make_state_dict(cfg, seed=3))
+        res = O.train_step(ref, cfg, x, forms, {})
+        want = torch.cat([v.reshape(-1) for v in ref.values()])
+        out["param_err"] = float((mine - want).abs().max())
+        out["norm"] = (float(total), res["total_norm"])
+        out["loss"] = (float(flat[-2] / count), res["loss"])
+        out["count"] = float(count)
+        out["replicas_identical"] = all(bool(torch.equal(g, gathered[0])) for g in gathered)
+        out["shards"] = [shard_batch(n_rows, r_, world) for r_ in range(world)]
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_eight_rank_step_equals_single_process_oracle_step(overlap):
+    """The N = 8 case the driver runs on a whole node, rehearsed on the CPU (gloo, world size 8): 509 ragged rows -> 8
+    shards, one flat-buffer all-reduce (or its two pieces), global-count division, clip by the global norm, Adam: every
+    replica ends with the SAME parameters, within 1e-5 of the single-process oracle step on the full batch.
+    When an 8-GPU node exists the only new thing it exercises is RCCL itself."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_step_worker, args=(8, _free_port(), out, overlap), nprocs=8, join=True)
+    sizes = [hi - lo for lo, hi in out["shards"]]
+    assert sum(sizes) == 509 and sorted(set(sizes)) == [63, 64]
+    assert out["replicas_identical"]
+    assert abs(out["loss"][0] - out["loss"][1]) <= 1e-5 * max(1.0, abs(out["loss"][1])), dict(out)
+    assert abs(out["norm"][0] - out["norm"][1]) <= 1e-5 * max(1.0, out["norm"][1]), dict(out)
+    assert out["param_err"] <= 1e-5, dict(out)
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_card_rehearsal():
     """`python bench.py --gpus 2` with no launcher around it (the self-launch path) as a one-card rehearsal: two ranks
