@@ -13,10 +13,13 @@ loop of 150 steps -> token ids copied to (pinned) host memory.  Inference shards
 collective (images are independent), so N GPUs run N replicas on different batches
 ("scaling": "weak"); value = all ranks' tokens / max-over-ranks time.
 
-Timed region (default since r03): K batches through GreedyPipeline -- two HIP streams, the decode of batch i on the
-8-member grouped kernel (decode_group8_kernel: one wave per SIMD and 80 KB of LDS per CU) while the conv workgroups of
-batch i + 1's encoder run on the SAME CUs (the decode is bound by L2 round trips, the encoder by the matrix pipe: they
-share the chip by resource).  Every batch still runs the full encoder, prepare, 150 decode steps and the id copy, and
+Timed region (default since r03): K batches through GreedyPipeline -- two HIP streams, the decode of batch i on a grouped
+kernel with one wave per SIMD (r04 default: decode_group16_kernel, 16 members x 16 rows, per-step products as split-bf16
+MFMA bursts; --decode-members 8: r03's decode_group8_kernel on the vector ALUs) while the conv workgroups of batch i + 1's
+encoder run on the SAME CUs (the decode is bound by L2 round trips, the encoder by the matrix pipe: they share the chip by
+resource).  encoder(i + 1) is held back until decode(i) reports itself resident (a dependency, not a delay).  The
+`roofline` object describes THIS region's dominant kernel from HIP events recorded on the decode stream around each of
+its K launches; `roofline.serial` is the serial pass's view, `schedule` says which schedule the two streams were in.  Every batch still runs the full encoder, prepare, 150 decode steps and the id copy, and
 all K batches complete inside the timed region.  A second, SERIAL pass of K batches (one stream, each kernel alone on
 the chip, the 4-member grouped decode) follows: it provides the per-kernel times of the roofline object, `value_serial`,
 and a floor -- `value` is never worse than it.  --serial times only that pass (the r02 default).
@@ -93,6 +96,10 @@ def main():
                     help="pipelined region on the r01 scheme (row-per-workgroup decode on half of the CUs) instead of the "
                          "co-resident one: decode of batch i on the 8-member grouped kernel (one wave per SIMD, 80 KB of LDS per "
                          "CU), the conv workgroups of batch i + 1's encoder on the same CUs")
+    ap.add_argument("--decode-members", type=int, choices=[8, 16], default=16,
+                    help="co-resident pipelined region: the grouped decode kernel -- 8 members x 8 rows per group on the vector ALUs "
+                         "(decode_group8_kernel, v_pk_fma_f32) or 16 members x 16 rows on the matrix cores (decode_group16_kernel, "
+                         "split-bf16 v_mfma_f32_16x16x32_bf16 bursts)")
     ap.add_argument("--decode-priority", type=int, default=-1, help="pipelined region: HIP stream priority of the decode stream (-1 = high)")
     ap.add_argument("--encoder-priority", type=int, default=0, help="pipelined region: HIP stream priority of the encoder stream(s)")
     ap.add_argument("--pipe-no-hold", action="store_true",
@@ -120,6 +127,8 @@ def main():
     args = ap.parse_args()
     args.pipelined = not args.serial
     args.coresident = not args.no_coresident
+    args.group_flag = _lib.FLAG_DECODE_GROUP16 if args.decode_members == 16 else _lib.FLAG_DECODE_GROUP8
+    args.group_kernel = f"decode_group{args.decode_members}_kernel"
 
     if args.launch_probe:
         os.environ.setdefault("I2L_DIST_BACKEND", "gloo")
@@ -230,7 +239,7 @@ def main():
     else:
         pipe = GreedyPipeline(model, synth.START, synth.END, T, depth=args.pipe_depth,
                               rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
-                              decode_flags=_lib.FLAG_DECODE_GROUP8 if args.coresident else 0,
+                              decode_flags=args.group_flag if args.coresident else 0,
                               decode_priority=args.decode_priority, encoder_streams=args.pipe_encoders or 1,
                               encoder_priority=args.encoder_priority, hold_encoder=False if args.pipe_no_hold else None)
 
@@ -321,10 +330,13 @@ def main():
         the P / Genc tables by `prepare`), and every one of its steps waits on two exchanges between the workgroups of a
         group through L2: a latency chain."""
         tf = costs["decode"]["flops"] / ms / 1e9
+        on_mfma = members == 16
         return dict(kernel=kernel, bound="latency", achieved=round(tf, 3), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
                     frac=round(tf / PEAK_FP32_TFLOPS, 4), launch_ms=round(ms, 4),
-                    traffic=tj.get("decode8" if members == 8 else "decode"), traffic_from=traffic_from,
-                    priced_against="mfma (fp32 peak; the kernel itself uses v_pk_fma_f32 on the vector ALUs, same 157.3 TFLOP/s peak)",
+                    traffic=tj.get({4: "decode", 8: "decode8", 16: "decode16"}[members]), traffic_from=traffic_from,
+                    priced_against="mfma (fp32 peak); the kernel's products run " + ("as split-bf16 v_mfma_f32_16x16x32_bf16 (6 bf16 "
+                    "partial products per fp32 product: 4.7 MFLOP/token executed on the bf16 pipe)" if on_mfma else
+                    "as v_pk_fma_f32 on the vector ALUs, same 157.3 TFLOP/s peak"),
                     executed_tflops=round(run_flops / ms / 1e9, 3),
                     frac_executed=round(run_flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4),
                     us_per_decode_step=round(ms * 1e3 / executed_steps_holder[0], 3),
@@ -346,7 +358,7 @@ def main():
     schedule = None
     timed_is_pipeline = (not args.serial) and args.coresident and pipelined_elapsed is not None and elapsed == pipelined_elapsed
     if (not args.serial) and args.coresident:
-        # ---- the TIMED region's dominant kernel: decode_group8_kernel, from the HIP events GreedyPipeline recorded on the decode
+        # ---- the TIMED region's dominant kernel (decode_group16_kernel / decode_group8_kernel), from the HIP events GreedyPipeline recorded on the decode
         # stream around each of the K launches of the timed region (the launch = a memset node of the exchange region + the
         # kernel); beside it the encoder chain of the same region and the schedule the two streams were in
         dec_ms = np.array([r["dec_start"].elapsed_time(r["dec_end"]) for r in pipe_trace])
@@ -358,17 +370,17 @@ def main():
         with torch.no_grad():     # the same kernel alone on the chip
             enc_ = model.encoder(images)
             for _ in range(3):
-                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8)
+                model.greedy_ids(enc_, synth.START, synth.END, T, flags=args.group_flag)
             prep = model.decoder.prepare(enc_)
             prepared = (prep[0], prep[1], prep[2], model.decoder._ws)
             ev8 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ev8[0].record()
             for _ in range(10):
-                model.greedy_ids(enc_, synth.START, synth.END, T, flags=_lib.FLAG_DECODE_GROUP8, prepared=prepared)
+                model.greedy_ids(enc_, synth.START, synth.END, T, flags=args.group_flag, prepared=prepared)
             ev8[1].record()
             torch.cuda.synchronize()
         alone_ms = ev8[0].elapsed_time(ev8[1]) / 10
-        pipe_view = decode_view("decode_group8_kernel", float(dec_ms.mean()), 8)
+        pipe_view = decode_view(args.group_kernel, float(dec_ms.mean()), args.decode_members)
         pipe_view.update(launch_ms_min_max=[round(float(dec_ms.min()), 4), round(float(dec_ms.max()), 4)],
                          alone_ms=round(alone_ms, 4), frac_alone=round(costs["decode"]["flops"] / alone_ms / 1e9 / PEAK_FP32_TFLOPS, 4),
                          stretch_beside_encoder=round(float(dec_ms.mean()) / alone_ms, 3),
@@ -427,8 +439,8 @@ def main():
                    "lstm_layers": cfg["lstm_layers"], "vocab": cfg["vocab_size"],
                    "parallelism": f"replicas x{world} (no collective)",
                    "batch_pipeline": "serial" if (args.serial or elapsed == serial_elapsed and pipelined_elapsed != serial_elapsed)
-                   else (f"2 streams, co-resident: decode(i) on decode_group8_kernel (8 members x 8 rows, one wave per SIMD, 80 KB of LDS "
-                         f"per CU) and the conv workgroups of encoder(i+1) share every CU; {args.pipe_depth} batches in flight"
+                   else (f"2 streams, co-resident: decode(i) on {args.group_kernel} ({args.decode_members} members x {args.decode_members} rows per "
+                         f"group, one wave per SIMD) and the conv workgroups of encoder(i+1) share every CU; {args.pipe_depth} batches in flight"
                          if args.coresident else
                          f"{1 + args.pipe_decoders} streams: encoder(i+1) beside decode(i), {args.pipe_rows} rows/workgroup, "
                          f"{args.pipe_depth} batches in flight")},
@@ -968,11 +980,11 @@ def extra_modes(args, world, rank, dev, dist):
                                   "timed region is inside the time)" if piped < elapsed else "serial")
         elapsed = min(elapsed, piped)
     if args.mode == "resnet" and not args.serial:
-        # the same co-resident two-stream schedule as the headline: decode(i) on decode_group8_kernel beside the trunk of
+        # the same co-resident two-stream schedule as the headline: decode(i) on the grouped co-resident kernel beside the trunk of
         # batch i + 1 (the ring GEMMs with a 2-stage ring fit beside it, the 4-stage ones wait); the serial pass above keeps
         # providing the encoder's time for the roofline and is a floor for `value`
         n_enc = args.pipe_encoders or 2
-        pipe = GreedyPipeline(model, synth.START, synth.END, T, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8,
+        pipe = GreedyPipeline(model, synth.START, synth.END, T, rows_per_workgroup=0, decode_flags=args.group_flag,
                               decode_priority=args.decode_priority, encoder_streams=n_enc,
                               hold_encoder=False if args.pipe_no_hold else None)
 
@@ -994,7 +1006,7 @@ def extra_modes(args, world, rank, dev, dist):
         serial_value_note = round(units * args.steps / elapsed, 1)
         conf["value_serial"] = serial_value_note
         conf["value_pipelined"] = round(units * args.steps / piped, 1)
-        conf["batch_pipeline"] = (f"{n_enc + 1} streams, co-resident: decode(i) on decode_group8_kernel beside the ResNet trunk(s) of the "
+        conf["batch_pipeline"] = (f"{n_enc + 1} streams, co-resident: decode(i) on {args.group_kernel} beside the ResNet trunk(s) of the "
                                   f"next {n_enc} batch(es)"
                                   if piped < elapsed else "serial")
         elapsed = min(elapsed, piped)

@@ -34,6 +34,7 @@ struct Layout {
 
 // grouped decode (decode_group.inc.h): exchange granules [groups padded to 8][2][4][288] x 8 B + a status block
 constexpr size_t GROUP_XCHG_PER_GROUP = (size_t)2 * 4 * 288 * 8;
+constexpr size_t GROUP16_XCHG_BYTES = (size_t)2 * 16 * 288 * 8;   // decode_group16.inc.h: [2 parities][16 members][288 granules]
 constexpr size_t GROUP_STATUS_BYTES = 2048;
 inline bool group_shape_ok(int V, int H, int L) { return L == 1 && H == 256 && V <= 512; }
 
@@ -58,7 +59,9 @@ Layout make_layout(int rows, int V, int E, int H, int L) {
         o.xchg = off;
         const size_t x4 = (size_t)i2l_cdiv(o.n_groups, 8) * 8 * GROUP_XCHG_PER_GROUP;
         const size_t x8 = (size_t)i2l_cdiv(i2l_cdiv(rows, 8), 8) * 8 * (2 * GROUP_XCHG_PER_GROUP);   // 8 members x 8 rows (decode_group8)
-        o.xchg_bytes = GROUP_STATUS_BYTES + (x4 > x8 ? x4 : x8);
+        const size_t x16 = (size_t)i2l_cdiv(i2l_cdiv(rows, 16), 8) * 8 * GROUP16_XCHG_BYTES;         // 16 x 16 (decode_group16)
+        const size_t x48 = x4 > x8 ? x4 : x8;
+        o.xchg_bytes = GROUP_STATUS_BYTES + (x48 > x16 ? x48 : x16);
         off += i2l_align(o.xchg_bytes);
     }
     o.total = off;
@@ -398,6 +401,7 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned row
 
 #include "decode_group.inc.h"
 #include "decode_group8.inc.h"
+#include "decode_group16.inc.h"
 #include "beam_group.inc.h"
 
 // KR / KL > 0 (fast path for R == 1, L == 1, H <= 256: thread j owns hidden unit j for the whole loop):
@@ -1061,6 +1065,27 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
     if (rows_per_wg == 0 && lo.xchg_bytes && (select == I2L_SELECT_LOGITS || select == I2L_SELECT_SOFTMAX) && !h0 &&
         !h_out && !c_out &&
         steps >= 8 && steps <= 65000) {   // the candidate granule carries step + 1 in 16 bits
+        if ((flags & I2L_FLAG_DECODE_GROUP16) && !logits_out && !forced && ids_out) {
+            // sixteen members x sixteen rows, the per-step products on the matrix cores (decode_group16.inc.h)
+            static_assert(GROUP16_XCHG_PER_GROUP == GROUP16_XCHG_BYTES, "exchange region sizing");
+            GroupParams gp{};
+            gp.w = p.w; gp.B = rows; gp.T = steps; gp.n_groups = i2l_cdiv(rows, 16);
+            gp.tok0 = tok0; gp.forced = nullptr; gp.ids = ids_out; gp.logits = nullptr;
+            gp.temperature = temperature; gp.use_temp = p.use_temp; gp.stop = stop; gp.end_id = end_id;
+            char* xb = const_cast<char*>(base) + lo.xchg;
+            gp.status = reinterpret_cast<unsigned*>(xb);
+            gp.xchg = reinterpret_cast<u64_t*>(xb + GROUP_STATUS_BYTES);
+            gp.opts = group_opts(steps, flags);
+            gp.resident_flag = resident_flag; gp.resident_value = resident_value;
+            hipStream_t gs = i2l_s(stream);
+            static std::atomic<unsigned> attr16{0};
+            if (i2l_lds_attr(reinterpret_cast<const void*>(decode_group16_kernel), GRP16_LDS, attr16)) {
+                if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
+                hipLaunchKernelGGL(decode_group16_kernel, dim3(i2l_cdiv(gp.n_groups, 8) * 128), dim3(G16NT), GRP16_LDS, gs, gp);
+                I2L_CHECK_LAUNCH();
+                return I2L_OK;
+            }
+        }
         if ((flags & I2L_FLAG_DECODE_GROUP8) && !logits_out && !forced && ids_out) {
             // eight members x eight rows: one wave per SIMD and ~80 KB of LDS per CU, i.e. room for a conv workgroup beside it
             static_assert(GROUP8_XCHG_PER_GROUP == 2 * GROUP_XCHG_PER_GROUP, "exchange region sizing");

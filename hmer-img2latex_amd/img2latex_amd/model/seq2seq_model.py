@@ -75,7 +75,8 @@ class Seq2SeqModel(nn.Module):
                    temperature: float = 1.0, stop: int = _lib.STOP_NONE, select: int = _lib.SELECT_LOGITS,
                    want_logits: bool = False, rows_per_workgroup: int = 0, flags: int = 0, prepared=None, resident=None):
         """Device-side greedy loop; returns (ids (B,T) int32 on device, logits or None).  ``flags``:
-        _lib.FLAG_DECODE_GROUP8 selects the 8-member grouped kernel (the one that shares a CU with a conv workgroup);
+        _lib.FLAG_DECODE_GROUP8 / _GROUP16 select the 8-member (vector ALUs) / 16-member (matrix cores) grouped kernels (the
+        ones that share a CU with a conv workgroup);
         ``prepared`` / ``resident``: see LSTMDecoder.run_steps."""
         B = encoder_output.shape[0]
         key = (B, int(start_token_id), encoder_output.device)

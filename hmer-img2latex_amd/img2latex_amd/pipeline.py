@@ -3,9 +3,11 @@
 Images are independent, so consecutive batches can overlap: the encoder of batch i + 1 runs on one HIP stream while the
 persistent decode loop of batch i runs on another.  Two ways of sharing the chip are built:
 
-* co-resident (r03, what bench.py times and Predictor uses): ``decode_flags = FLAG_DECODE_GROUP8`` -- the 8-member grouped
-  decode keeps one wave per SIMD and 80 KB of LDS on EVERY compute unit, which leaves room for one conv workgroup of the
-  next batch's encoder on the same unit: the two kernels share the chip by resource.  The encoder of batch i + 1 is held
+* co-resident (r03, what bench.py times and Predictor uses): ``decode_flags = FLAG_DECODE_GROUP16`` (r04: 16 members x 16
+  rows per group, the per-step products as split-bf16 MFMA bursts that resident conv waves barely stretch) or
+  ``FLAG_DECODE_GROUP8`` (r03: 8 x 8 on the vector ALUs) -- either keeps one wave per SIMD and 50 - 80 KB of LDS on EVERY
+  compute unit, which leaves room for one conv workgroup of the next batch's encoder on the same unit: the two kernels share
+  the chip by resource.  The encoder of batch i + 1 is held
   back until the decode of batch i owns its compute units -- a DEPENDENCY since r04: the decode kernel publishes a
   sequence number once all its groups are resident (i2l_greedy_decode_ex's residency signal) and the encoder stream
   waits for that word (i2l_stream_wait_value32); r03 guessed the moment with a 30 us delay kernel;
@@ -65,7 +67,7 @@ class GreedyPipeline:
         # `wait_timeout_us` bounds it (a launch that fell back to an ungrouped kernel publishes at once, a timed-out group
         # never does).
         if hold_encoder is None:
-            hold_encoder = bool(self.decode_flags & _lib.FLAG_DECODE_GROUP8)
+            hold_encoder = bool(self.decode_flags & (_lib.FLAG_DECODE_GROUP8 | _lib.FLAG_DECODE_GROUP16))
         self.hold_encoder = bool(hold_encoder)
         self.wait_timeout_us = float(wait_timeout_us)
         self._resident = torch.zeros(1, dtype=torch.int32, device=dev)

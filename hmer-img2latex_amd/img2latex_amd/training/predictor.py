@@ -203,7 +203,7 @@ class Predictor:
         start, end = self.tokenizer.start_token_id, self.tokenizer.end_token_id
         n_enc = 2 if hasattr(self.model.encoder, "_trunk_train") else 1      # ResNet trunk: two in flight
         pipe = GreedyPipeline(self.model, start, end, max_length, temperature, rows_per_workgroup=0,
-                              decode_flags=_lib.FLAG_DECODE_GROUP8, decode_priority=-1, encoder_streams=n_enc,
+                              decode_flags=_lib.FLAG_DECODE_GROUP16, decode_priority=-1, encoder_streams=n_enc,
                               stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX)
 
         def finish(ids_host):
@@ -333,7 +333,7 @@ class Predictor:
             with torch.no_grad():
                 ids, _ = self.model.greedy_ids(enc, tk.start_token_id, tk.end_token_id, T, stop=_lib.STOP_STICKY,
                                                select=_lib.SELECT_SOFTMAX, rows_per_workgroup=rows_per_workgroup,
-                                               flags=_lib.FLAG_DECODE_GROUP8 if coresident else 0, prepared=prepared,
+                                               flags=_lib.FLAG_DECODE_GROUP16 if coresident else 0, prepared=prepared,
                                                resident=(st["resident"], st["n"]) if coresident else None)
                 _lib.check(L.i2l_compact_ids(ids.data_ptr(), B, T, ids.stride(0), int(tk.end_token_id),
                                              self._drop.data_ptr(), len(drop), p_ids.data_ptr(), W, p_len.data_ptr(),

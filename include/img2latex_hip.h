@@ -69,6 +69,11 @@ typedef void* i2l_stream_t;
                                           with EIGHT members x EIGHT rows per group -- one wave per SIMD and ~80 KB of LDS
                                           per CU instead of two waves and 140 KB, so that a conv workgroup of the NEXT
                                           batch's encoder fits beside it; same ids                                   */
+#define I2L_FLAG_DECODE_GROUP16 0x8000 /* i2l_greedy_decode_ex (ids only): the grouped kernel with SIXTEEN members x SIXTEEN rows per
+                                          group and the per-step products (LSTM gates, logits) on the matrix cores as split-bf16
+                                          v_mfma_f32_16x16x32_bf16 bursts (fp32-grade: 3 bf16 pieces per operand, 6 partial
+                                          products) -- ~250 registers and 49 KB of LDS per CU, and a burst that conv waves on
+                                          the same CU barely stretch; same ids up to fp32 near-ties.  Wins over _GROUP8 if both set */
 #define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
                                           implicit-im2col GEMM instead of the sparse first-block kernel (A/B, tests)   */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */

