@@ -305,6 +305,43 @@ extern "C" int i2l_sequence_metrics(const int32_t* pred, const int32_t* pred_len
     return I2L_OK;
 }
 
+// Host helper (no GPU work): the float64 tail of calculate_metrics (metrics.py:184-223) on the kernel's integer statistics.
+// stats (pairs, stride) int32 rows = [lev, match 1..4, (2 unused), gen_len, true_len] as device_sequence_statistics packs
+// them.  Every float64 operation is the reference's, in its order (metrics.py:85-94,113-181): one division per precision,
+// logs added left to right from 0.0, one division by n, one exp, the brevity factor multiplied from the left, means as
+// left-to-right sums -- libm's log / exp are the functions CPython's math module calls, so the scores are bit-identical to
+// the Python formulas (tests) at a hundredth of their cost (0.5 ms per 256 pairs in the interpreter).
+extern "C" int i2l_scores_from_statistics(const int32_t* stats, int pairs, int stride, int n, double* bleu_mean_out,
+                                          double* lev_mean_out) {
+    if (!stats || pairs <= 0 || stride < 9 || n < 1 || n > 4 || !bleu_mean_out || !lev_mean_out) return I2L_ERR_ARG;
+    double bleu_sum = 0.0, lev_sum = 0.0;
+    for (int i = 0; i < pairs; ++i) {
+        const int32_t* r = stats + (size_t)i * stride;
+        const int lev = r[0], gen_len = r[7], true_len = r[8];
+        double bleu = 0.0;
+        const int shorter = gen_len < true_len ? gen_len : true_len;
+        if (shorter != 0) {
+            double log_sum = 0.0;
+            bool zero = false;
+            for (int g = 1; g <= n; ++g) {
+                const int hits = shorter >= g ? r[g] : 0;
+                if (hits == 0) { zero = true; break; }
+                log_sum += log((double)hits / (double)(gen_len - g + 1));
+            }
+            if (!zero) {
+                const double score = exp(log_sum / (double)n);
+                bleu = gen_len >= true_len ? score : exp(1.0 - (double)true_len / (double)gen_len) * score;
+            }
+        }
+        bleu_sum += bleu;
+        const int max_length = gen_len > true_len ? gen_len : true_len;
+        lev_sum += max_length == 0 ? 1.0 : 1.0 - ((double)lev / (double)max_length);
+    }
+    *bleu_mean_out = bleu_sum / (double)pairs;
+    *lev_mean_out = lev_sum / (double)pairs;
+    return I2L_OK;
+}
+
 extern "C" int i2l_masked_accuracy(const float* logits, const int64_t* targets, int64_t rows, int vocab, int64_t pad_id,
                                    uint64_t* correct_total_out, i2l_stream_t stream) {
     if (!logits || !targets || !correct_total_out || rows <= 0 || vocab <= 0) return I2L_ERR_ARG;

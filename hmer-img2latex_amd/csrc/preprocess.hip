@@ -7,6 +7,7 @@
 // the HOST in double precision with libm's sin -- i2l_lanczos_coeffs below, the same arithmetic Pillow runs -- so the
 // device work is pure integer and the result is bit-identical to the reference's.
 #include <math.h>
+#include <string.h>
 
 #include <thread>
 #include <vector>
@@ -35,6 +36,65 @@ double bicubic_filter(double x) {
     return 0.0;
 }
 double filter_support(int filter) { return filter == I2L_FILTER_BICUBIC ? 2.0 : 3.0; }
+
+// ---- the same tables built ON THE DEVICE (r04): one thread per (table, output sample) repeats the host function's
+// double-precision arithmetic operation by operation (no contraction into FMAs: the host build has none).  The one
+// difference is sin(): the device's (ocml) and libm's are both faithfully rounded but not the same function, so a
+// weight can differ by one unit of 2^-22 where the normalised value sits within ~1e-16 of a rounding boundary (odds
+// ~1e-9 per weight).  The host function stays the Pillow-identical reference; tests hold the device tables equal to it.
+#pragma clang fp contract(off)
+__device__ double sinc_filter_d(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * M_PI;
+    return sin(x) / x;
+}
+__device__ double resample_weight_d(int filter, double x) {
+    if (filter == I2L_FILTER_BICUBIC) {
+        const double a = -0.5;
+        if (x < 0.0) x = -x;
+        if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+        if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+        return 0.0;
+    }
+    if (-3.0 <= x && x < 3.0) return sinc_filter_d(x) * sinc_filter_d(x / 3);
+    return 0.0;
+}
+__global__ __launch_bounds__(64) void resample_coeffs_kernel(int filter, const int32_t* __restrict__ in_sizes,
+                                                             const int32_t* __restrict__ out_sizes,
+                                                             const int64_t* __restrict__ offsets, int32_t* __restrict__ tables) {
+    const int i = blockIdx.y;
+    const int in_size = in_sizes[i], out_size = out_sizes[i];
+    const float in0 = 0.0f, in1 = (float)in_size;
+    double filterscale, scale;
+    filterscale = scale = (double)(in1 - in0) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = (filter == I2L_FILTER_BICUBIC ? 2.0 : 3.0) * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    const double ss = 1.0 / filterscale;
+    int32_t* bounds = tables + offsets[i];
+    int32_t* kk_all = bounds + 2 * (int64_t)out_size;
+    for (int xx = blockIdx.x * 64 + threadIdx.x; xx < out_size; xx += gridDim.x * 64) {
+        const double center = in0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) ww += resample_weight_d(filter, (x + xmin - center + 0.5) * ss);
+        int32_t* kk = kk_all + (size_t)xx * ksize;
+        int x;
+        for (x = 0; x < xmax; ++x) {
+            double k = resample_weight_d(filter, (x + xmin - center + 0.5) * ss);
+            if (ww != 0.0) k /= ww;
+            kk[x] = k < 0 ? (int)(-0.5 + k * (1 << PREC)) : (int)(0.5 + k * (1 << PREC));
+        }
+        for (; x < ksize; ++x) kk[x] = 0;
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+}
+#pragma clang fp contract(fast)
 
 // value of converted-mode pixel (y, x, band c) of the source image: utils.py:45-49 img.convert("L" / "RGB")
 __device__ __forceinline__ int src_px(const uint8_t* __restrict__ img, int w, int src_c, int out_c, int y, int x, int c) {
@@ -235,6 +295,45 @@ extern "C" int i2l_resample_coeffs_batch(int filter, int n, const int32_t* in_si
         for (auto& th : pool) th.join();
     }
     for (int i = 0; i < n; ++i) if (rc[i] != I2L_OK) return rc[i];
+    return I2L_OK;
+}
+
+extern "C" int i2l_resample_coeffs_device(int filter, int n, const int32_t* in_sizes, const int32_t* out_sizes,
+                                          const int64_t* offsets, int32_t* tables, int max_out_size, i2l_stream_t stream) {
+    if (n <= 0 || n > 65535 || !in_sizes || !out_sizes || !offsets || !tables || max_out_size <= 0) return I2L_ERR_ARG;
+    if (filter != I2L_FILTER_LANCZOS && filter != I2L_FILTER_BICUBIC) return I2L_ERR_UNSUPPORTED;
+    int bx = (max_out_size + 63) / 64;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(resample_coeffs_kernel, dim3(bx, n), dim3(64), 0, i2l_s(stream), filter, in_sizes, out_sizes, offsets, tables);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+// n host buffers -> one (pinned) block, on up to `threads` host threads that live for the call: the ragged pages of a batch
+// are separate arrays on the reference's side (PIL decodes them one by one); one thread copies 16 MB in ~3 ms
+extern "C" int i2l_pack_host(const void* const* srcs, const int64_t* sizes, const int64_t* offsets, int n, void* dst, int threads) {
+    if (n < 0 || (n > 0 && (!srcs || !sizes || !offsets || !dst))) return I2L_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (sizes[i] < 0 || offsets[i] < 0 || (sizes[i] > 0 && !srcs[i])) return I2L_ERR_ARG;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) total += sizes[i];
+    int nt = threads < 1 ? 1 : threads;
+    if (total < (1 << 20) || n < 2) nt = 1;
+    if (nt > n) nt = n;
+    auto work = [&](int t) {                                  // contiguous runs of images with about total / nt bytes each
+        const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+        int64_t acc = 0;
+        for (int i = 0; i < n; ++i) {
+            if (acc >= lo && acc < hi && sizes[i] > 0) memcpy(static_cast<char*>(dst) + offsets[i], srcs[i], (size_t)sizes[i]);
+            acc += sizes[i];
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
     return I2L_OK;
 }
 

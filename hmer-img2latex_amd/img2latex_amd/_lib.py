@@ -134,6 +134,9 @@ _SIGNATURES.update({
     "i2l_resample_ksize": (c_int, [c_int, c_int, c_int]),
     "i2l_resample_coeffs": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "i2l_resample_coeffs_batch": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "i2l_scores_from_statistics": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double)]),
+    "i2l_resample_coeffs_device": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "i2l_pack_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "i2l_resize_bilinear_f32": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p]),
 })
 FILTER_LANCZOS, FILTER_BICUBIC = 1, 3          # include/img2latex_hip.h I2L_FILTER_* (= PIL.Image.Resampling values)

@@ -100,7 +100,7 @@ def train(config_path: str = "img2latex/configs/config.yaml", experiment_name: s
             vocab = {"<PAD>": 0, "<START>": 1, "<END>": 2, "<UNK>": 3}
             vocab.update({f"t{i}": i for i in range(4, synthetic_vocab)})
             tokenizer = TokenTable(vocab, max_sequence_length=int(config.get("data", {}).get("max_seq_length", 150)))
-        epochs, loaders = 1, None
+        max_epochs, loaders = None, None                                    # one pass over the synthetic batches
     else:
         try:
             from img2latex.data.dataset import create_data_loaders          # the reference's own dataset + tokenizer
@@ -112,7 +112,7 @@ def train(config_path: str = "img2latex/configs/config.yaml", experiment_name: s
         tokenizer = LaTeXTokenizer(max_sequence_length=config["data"]["max_seq_length"])
         tokenizer.fit_on_formulas_file(os.path.join(config["data"]["data_dir"], config["data"]["formulas_file"]))
         loaders = create_data_loaders(config=config, tokenizer=tokenizer, max_samples=None)
-        epochs = int(tcfg.get("epochs", 1))
+        max_epochs = int(tcfg.get("epochs", 50))                            # trainer.py:118
     model = build_model(config, tokenizer.vocab_size)
     if resume is not None:
         model.load_state_dict(resume["model_state_dict"])                   # trainer.py:253
@@ -122,12 +122,18 @@ def train(config_path: str = "img2latex/configs/config.yaml", experiment_name: s
                    label_smoothing=0.1, seed=seed)                          # trainer.py:91-93,111-115
     if resume is not None and resume.get("optimizer_state_dict"):
         ts.load_optimizer_state_dict(resume["optimizer_state_dict"])        # trainer.py:255
+    # trainer.py:257-258,697: a checkpoint's "epoch" is the number of COMPLETED epochs and "step" the global step; a resumed
+    # run continues both and stops at the configured total (it used to restart the step count and always run
+    # `epochs` more epochs)
     start_epoch = int(resume.get("epoch", 0)) if resume is not None else 0
+    step0 = step = int(resume.get("step", 0)) if resume is not None else 0
+    if max_epochs is None:
+        max_epochs = start_epoch + 1
     ck_dir = os.path.join(output_dir, experiment_name, "checkpoints")
     os.makedirs(ck_dir, exist_ok=True)
-    step, last, path = 0, None, None
+    last, path = None, None
     is_resnet = config["model"]["name"] == "resnet_lstm"
-    for epoch in range(start_epoch + 1, start_epoch + epochs + 1):
+    for epoch in range(start_epoch + 1, max_epochs + 1):                    # `epoch` = trainer.py's current_epoch + 1
         batches = _synthetic_batches(config, synthetic_steps, tokenizer.vocab_size, seed) if loaders is None else loaders["train"]
         for batch in batches:
             images = batch["images"].to(dev)                                # data/utils.py:113-135 prepare_batch
@@ -140,7 +146,8 @@ def train(config_path: str = "img2latex/configs/config.yaml", experiment_name: s
         save_checkpoint(path, model, tokenizer, config, epoch=epoch, step=step, metrics={"loss": loss},
                         optimizer_state_dict=ts.optimizer_state_dict())
         print(f"epoch {epoch}: {step} steps, loss {loss:.4f}, checkpoint {path}")
-    return {"loss": float(last["loss"]) if last is not None else None, "steps": step, "checkpoint": path}
+    return {"loss": float(last["loss"]) if last is not None else None, "steps": step - step0, "global_step": step,
+            "checkpoint": path}
 
 
 def main(argv: Optional[List[str]] = None) -> int:

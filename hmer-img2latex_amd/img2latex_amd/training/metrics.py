@@ -141,6 +141,19 @@ def calculate_metrics(predictions: List[List[int]], targets: List[List[int]]) ->
     return metrics_from_statistics(sequence_statistics(predictions, targets, 4))
 
 
+def metrics_from_packed(packed_host: torch.Tensor) -> Dict[str, float]:
+    """The float64 tail of calculate_metrics on the (P, >= 9) int32 host rows of device_sequence_statistics(defer=True), by
+    the library's host helper (i2l_scores_from_statistics: the formulas below, operation by operation, without the
+    interpreter: 0.5 ms -> 5 us per 256 pairs; ``metrics_from_statistics`` is the Python statement of the same thing)."""
+    import ctypes
+    if packed_host.dtype != torch.int32 or packed_host.dim() != 2 or packed_host.shape[1] < 9 or packed_host.stride(1) != 1:
+        raise TypeError("packed statistics must be a (P, >= 9) int32 host tensor with contiguous rows")
+    b, l = ctypes.c_double(), ctypes.c_double()
+    _lib.check(_lib.lib().i2l_scores_from_statistics(packed_host.data_ptr(), packed_host.shape[0], packed_host.stride(0), 4,
+                                                     ctypes.byref(b), ctypes.byref(l)), "scores_from_statistics")
+    return {"bleu": b.value, "levenshtein": l.value, "batch_size": int(packed_host.shape[0])}
+
+
 def metrics_from_statistics(st: Dict[str, torch.Tensor]) -> Dict[str, float]:
     """The float64 tail of calculate_metrics on the kernel's integer statistics (host tensors)."""
     match, lev = st["match"].tolist(), st["lev"].tolist()

@@ -237,22 +237,26 @@ class Predictor:
         (device tensors) for callers that also want the strings."""
         return self._evaluate_finish(self._evaluate_launch(images, targets, max_length))
 
-    def evaluate_stream(self, batches, max_length: Optional[int] = None):
+    def evaluate_stream(self, batches, max_length: Optional[int] = None, lookahead: int = 2):
         """``evaluate_batch`` over an iterable of (images, targets), one result per batch in order, software-pipelined:
         the host work of batch i+1 (shape pass, packing the ragged pages into pinned memory, their upload on a side
         stream) runs while the device is still busy with batch i, and the host only waits for batch i's statistics
         after batch i+1 has been enqueued.  On the device the two batches in flight share the GPU the way GreedyPipeline's
         do: preprocessing + encoder + decoder prepare of batch i+1 on one stream, the decode (8-member grouped kernel) +
-        id compaction + statistics of batch i on another, the first held back until the second's decode has been launched.
+        id compaction + statistics of batch i on another, the first held back until the second's decode is resident.
+        ``lookahead`` batches are enqueued beyond the one whose statistics the host waits for (r04: 2 -- with 1 the host only
+        began batch i + 2 once batch i had finished, its 0.7 ms of packing then landed inside decode(i + 1), and the
+        encoder of batch i + 2 started where that decode ended instead of beside it: profiles/r04/evaluate_chain.txt).
         This is the loop of cli.py:449-495."""
-        pending = None
+        from collections import deque
+        pending = deque()
+        lookahead = max(1, min(int(lookahead), 2))           # the landing buffers / decoder slots rotate over 4 / 3
         for images, targets in batches:
-            handle = self._evaluate_launch(images, targets, max_length, side_upload=True, coresident=True)
-            if pending is not None:
-                yield self._evaluate_finish(pending)
-            pending = handle
-        if pending is not None:
-            yield self._evaluate_finish(pending)
+            pending.append(self._evaluate_launch(images, targets, max_length, side_upload=True, coresident=True))
+            if len(pending) > lookahead:
+                yield self._evaluate_finish(pending.popleft())
+        while pending:
+            yield self._evaluate_finish(pending.popleft())
 
     def _evaluate_launch(self, images, targets: torch.Tensor, max_length: Optional[int], side_upload: bool = False,
                          rows_per_workgroup: int = 0, coresident: bool = False):
@@ -364,7 +368,7 @@ class Predictor:
             raw, targets, max_length = h["raw"]
             return self._evaluate_finish(self._evaluate_launch(raw, targets, max_length, rows_per_workgroup=1))
         _lib.check_ids(host[:, 9:10])
-        out = M.metrics_from_statistics(M.unpack_statistics(host[:, :9]))
+        out = M.metrics_from_packed(host)
         out["pred_ids"], out["pred_len"] = h["p_ids"], h["p_len"]
         return out
 

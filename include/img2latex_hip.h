@@ -438,6 +438,13 @@ int i2l_sequence_metrics(const int32_t* pred, const int32_t* pred_len, int pred_
                          const int32_t* target_len, int target_stride, int pairs, int max_len, int max_n,
                          int pad_id, int32_t* lev_out, int32_t* match_out, int32_t* tla_out, i2l_stream_t stream);
 
+/* Host helper (no GPU work): mean BLEU-n and mean Levenshtein similarity (calculate_metrics, metrics.py:184-223) from the
+ * integer statistics of i2l_sequence_metrics, `pairs` rows of `stride` >= 9 int32 = [lev, match 1..4, 2 unused, gen_len,
+ * true_len].  The reference's float64 formulas operation by operation (libm log / exp = CPython's math.log / math.exp):
+ * bit-identical scores without 256 x 2 interpreter calls per batch. */
+int i2l_scores_from_statistics(const int32_t* stats, int pairs, int stride, int n, double* bleu_mean_out,
+                               double* lev_mean_out);
+
 /* The id post-processing between the decode loop and the metrics, on the device (cli.py:466-481 with
  * predictor.py:350-358,384-391 and tokenizer.py:166-192): per row keep, in order, the ids BEFORE the first stop
  * position -- id == end_id, or id < 0 (the sticky stop rule's filler) -- that are not one of drop_ids[0..n_drop)
@@ -480,6 +487,20 @@ int i2l_resample_coeffs(int filter, int in_size, int out_size, int32_t* bounds_o
  * offsets[i] as bounds (out, 2) followed by weights (out, ksize).  No global state: the threads live for the call. */
 int i2l_resample_coeffs_batch(int filter, int n, const int32_t* in_sizes, const int32_t* out_sizes,
                               const int64_t* offsets, int32_t* out, int threads);
+
+/* The same tables built ON THE DEVICE for n resamplings at once (in_sizes / out_sizes / offsets are DEVICE arrays; entry i
+ * is written at tables + offsets[i] as i2l_resample_coeffs_batch lays it out; max_out_size = the largest out_sizes[i]):
+ * the host function's double-precision arithmetic repeated operation by operation, with the device's sin() in place of
+ * libm's -- both faithfully rounded, so a 22-bit weight can differ by one unit where the normalised value sits within
+ * ~1e-16 of a rounding boundary (about once in 1e9 weights).  i2l_resample_coeffs stays the Pillow-identical reference.
+ * A batch of ragged pages then uploads nothing but its pixels, sizes and plans (the host-side tables cost
+ * more than the device chain). */
+int i2l_resample_coeffs_device(int filter, int n, const int32_t* in_sizes, const int32_t* out_sizes, const int64_t* offsets,
+                               int32_t* tables, int max_out_size, i2l_stream_t stream);
+/* Host helper (no GPU work): copies n host buffers srcs[i] (sizes[i] bytes) to dst + offsets[i] on up to `threads` host
+ * threads that live for the call -- the separate page arrays PIL hands the reference's load_image, gathered into the
+ * one pinned block that is uploaded. */
+int i2l_pack_host(const void* const* srcs, const int64_t* sizes, const int64_t* offsets, int n, void* dst, int threads);
 
 /* One image of a ragged batch.  Offsets index `pixels` (bytes), `tables` (int32 elements) and the workspace
  * (bytes).  Bounds are ABSOLUTE source indices as i2l_resample_coeffs writes them; when need_h the kernel itself

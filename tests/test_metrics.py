@@ -160,3 +160,31 @@ def test_bit_vector_levenshtein_block_boundaries(width):
             p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
             assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), (width, alpha, i, pl[i], tl[i])
             assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), (width, alpha, i)
+
+
+def test_scores_host_helper_is_bit_identical_to_the_python_formulas():
+    """i2l_scores_from_statistics (r04: the float64 tail of calculate_metrics in the library's host code, so that the evaluate
+    chain does not spend 0.5 ms per batch in the interpreter) == metrics_from_statistics (the reference's formulas, metrics.py:
+    85-94,113-181, in Python) on random statistics with the edge cases: empty prediction / target, zero n-gram hits,
+    sequences shorter than n, brevity penalty on and off; padded rows (stride 10, as Predictor's landing buffer)."""
+    import torch
+    from img2latex_amd.training import metrics as M
+    rng = np.random.default_rng(5)
+    P = 600
+    gl = rng.integers(0, 160, P)
+    tl = rng.integers(0, 160, P)
+    gl[:8] = [0, 0, 5, 3, 2, 1, 150, 150]
+    tl[:8] = [0, 7, 0, 3, 9, 1, 150, 149]
+    match = np.stack([rng.integers(0, np.maximum(gl - g, 0) + 1) for g in range(4)], axis=1)
+    match[rng.random(P) < 0.2, 3] = 0
+    lev = rng.integers(0, np.maximum(np.maximum(gl, tl), 1) + 1)
+    packed = np.zeros((P, 10), np.int32)
+    packed[:, 0], packed[:, 1:5], packed[:, 7], packed[:, 8], packed[:, 9] = lev, match, gl, tl, 12345
+    host = torch.from_numpy(packed)
+    want = M.metrics_from_statistics(M.unpack_statistics(host[:, :9]))
+    got = M.metrics_from_packed(host)
+    assert got == want, (got, want)                                   # float64 equality, not closeness
+    one = M.metrics_from_packed(host[6:7])
+    assert one == M.metrics_from_statistics(M.unpack_statistics(host[6:7, :9]))
+    with pytest.raises(TypeError):
+        M.metrics_from_packed(host[:, :5])

@@ -151,6 +151,9 @@ def test_cli_predict_and_train(tmp_path):
     out = cli.train(str(cfg_path), "cli_test", PT, None, "cuda", 7, synthetic_steps=3, output_dir=str(tmp_path / "outputs"))
     assert out["steps"] == 3 and np.isfinite(out["loss"]) and os.path.exists(out["checkpoint"])
     again = torch.load(out["checkpoint"], map_location="cpu", weights_only=False)
+    # trainer.py:257-258,697: the resumed run continues the checkpoint's counters (completed epochs, global step)
+    assert again["epoch"] == ck["epoch"] + 1 and again["step"] == ck["step"] + 3 == out["global_step"]
+    assert os.path.basename(out["checkpoint"]) == f"checkpoint_epoch_{again['epoch']}_step_{again['step']}.pt"
     assert set(again) == set(ck) and again["optimizer_state_dict"]["state"][0]["step"].item() == 3.0
     assert isinstance(cli.predict(out["checkpoint"], PNG, max_length=10), str)
     assert cli.main(["train", "--config-path", str(tmp_path / "missing.yaml"), "--synthetic-steps", "1"]) == 1   # cli.py:247-250
