@@ -290,13 +290,16 @@ class Predictor:
             if "enc" not in st:
                 st["enc"] = torch.cuda.Stream(self.device)
                 st["dec"] = torch.cuda.Stream(self.device, priority=-1)
+                st["stat"] = torch.cuda.Stream(self.device)  # id compaction + statistics + their copy home (r04): off the decode
+                                                             # stream, which then goes from decode(i) straight into decode(i + 1)
                 st["resident"], st["n"] = torch.zeros(1, dtype=torch.int32, device=self.device), 0
-            s_enc, s_dec = st["enc"], st["dec"]
+            s_enc, s_dec, s_stat = st["enc"], st["dec"], st["stat"]
             s_enc.wait_stream(cur)                           # the caller's tensors, tgt, the constants
             on_enc = lambda: torch.cuda.stream(s_enc)
             on_dec = lambda: torch.cuda.stream(s_dec)
+            on_stat = lambda: torch.cuda.stream(s_stat)
         else:
-            on_enc = on_dec = contextlib.nullcontext
+            on_enc = on_dec = on_stat = contextlib.nullcontext
         with on_enc():
             if coresident and st["n"] > 0:                   # not before the previous batch's decode owns its compute units
                 _lib.check(L.i2l_stream_wait_value32(st["resident"].data_ptr(), st["n"], 20000.0, _lib.stream_ptr()),
@@ -332,13 +335,22 @@ class Predictor:
                 s_dec.wait_event(enc_done)
                 for t_ in (x, tgt, t_ids, t_len, enc):
                     t_.record_stream(s_dec)                  # allocated on the first stream, read on the second
-            p_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
-            p_len = torch.empty((B,), dtype=torch.int32, device=dev)
             with torch.no_grad():
                 ids, _ = self.model.greedy_ids(enc, tk.start_token_id, tk.end_token_id, T, stop=_lib.STOP_STICKY,
                                                select=_lib.SELECT_SOFTMAX, rows_per_workgroup=rows_per_workgroup,
                                                flags=_lib.FLAG_DECODE_GROUP16 if coresident else 0, prepared=prepared,
                                                resident=(st["resident"], st["n"]) if coresident else None)
+            if coresident:
+                decoded = torch.cuda.Event()
+                decoded.record(s_dec)
+        with on_stat(), torch.cuda.device(dev):
+            if coresident:
+                s_stat.wait_event(decoded)
+                for t_ in (ids, t_ids, t_len):
+                    t_.record_stream(s_stat)
+            p_ids = torch.zeros((B, W), dtype=torch.int32, device=dev)
+            p_len = torch.empty((B,), dtype=torch.int32, device=dev)
+            with torch.no_grad():
                 _lib.check(L.i2l_compact_ids(ids.data_ptr(), B, T, ids.stride(0), int(tk.end_token_id),
                                              self._drop.data_ptr(), len(drop), p_ids.data_ptr(), W, p_len.data_ptr(),
                                              _lib.stream_ptr()), "compact_ids")
