@@ -28,7 +28,7 @@ constexpr int NT = 256;        // threads per workgroup
 constexpr int VCHUNK = 2 * NT;  // vocab columns per projection pass
 
 struct Layout {
-    size_t P, Genc, WhhT[MAXL], WihT[MAXL], biasP[MAXL], WoutT, boutP, gemm_ws, xchg, xchg_bytes, total;
+    size_t P, Genc, WhhT[MAXL], WihT[MAXL], biasP[MAXL], WoutT, boutP, wpack16, gemm_ws, xchg, xchg_bytes, total;
     int Vp, n_groups;
 };
 
@@ -51,6 +51,9 @@ Layout make_layout(int rows, int V, int E, int H, int L) {
     for (int l = 1; l < L; ++l) o.biasP[l] = take(G);
     o.WoutT = take((size_t)H * o.Vp);
     o.boutP = take(o.Vp);
+    // decode_group16_kernel: the weights pre-split into bf16 pieces in the matrix cores' operand layout, [member 16][wave 4]
+    // [fragment 36][lane 64] x 16 bytes (weight-only: built with the other weight images under I2L_PREP_WEIGHTS)
+    if (group_shape_ok(V, H, L)) o.wpack16 = take((size_t)16 * 4 * 36 * 64 * 4);
     size_t g1 = i2l_gemm_workspace_bytes(V, 4 * H, E), g2 = i2l_gemm_workspace_bytes(rows, 4 * H, E);
     o.gemm_ws = off;
     off += i2l_align(g1 > g2 ? g1 : g2);
@@ -110,6 +113,7 @@ struct StepWeights {
     const float* biasP[MAXL];
     const float* WoutT;
     const float* boutP;
+    const void* wpack16;      // decode_group16_kernel's operand image (null when the dimensions have no grouped path)
 };
 
 struct DecodeParams {
@@ -911,6 +915,7 @@ StepWeights step_weights(const Layout& lo, const char* base, int V, int H, int L
         w.biasP[l] = l > 0 ? F(lo.biasP[l]) : nullptr;
     }
     w.WoutT = F(lo.WoutT); w.boutP = F(lo.boutP);
+    w.wpack16 = lo.wpack16 ? base + lo.wpack16 : nullptr;
     return w;
 }
 
@@ -963,6 +968,11 @@ extern "C" int i2l_decoder_prepare(const i2l_decoder_weights* w, const float* en
         I2L_CHECK_LAUNCH();
         hipLaunchKernelGGL(bout_pad_kernel, dim3(i2l_cdiv(lo.Vp, 256)), dim3(256), 0, s, w->b_out, F(lo.boutP), V, lo.Vp);
         I2L_CHECK_LAUNCH();
+        if (lo.wpack16) {
+            hipLaunchKernelGGL(pack16_kernel, dim3(16 * 4), dim3(64), 0, s, F(lo.WhhT[0]), F(lo.WoutT),
+                               reinterpret_cast<u32x4_t*>(base + lo.wpack16));
+            I2L_CHECK_LAUNCH();
+        }
     }
     const size_t gws = lo.total - lo.gemm_ws;
     if (what & I2L_PREP_WEIGHTS) {   // P = Emb @ W_ih_0[:, :E]^T, gate-interleaved columns

@@ -78,6 +78,31 @@ __device__ __forceinline__ void load_run64(const u64_t* src, u32x4_t (&g)[4]) {
         : "memory");
 }
 
+// weight-only preparation (i2l_decoder_prepare, I2L_PREP_WEIGHTS): every (member, wave, lane)'s 36 operand fragments --
+// 24 of W_hh^T (8 k-steps x 3 pieces), 12 of W_out^T (4 k-steps x 3 pieces) -- split once and stored lane-contiguously, so
+// that the kernel's prologue is 36 coalesced 16-byte loads per lane instead of 192 strided 4-byte loads + 192 splits
+// (60 us of every launch, during which the next batch's encoder waits for the decode to report itself resident)
+__global__ __launch_bounds__(64) void pack16_kernel(const float* __restrict__ WhhT, const float* __restrict__ WoutT,
+                                                    u32x4_t* __restrict__ pack) {
+    const int m = blockIdx.x >> 2, wave = blockIdx.x & 3, lane = threadIdx.x;
+    const int lhi = lane >> 4, lcol = lane & 15, ltile = wave & 1, lhalf = wave >> 1;
+    u32x4_t* dst = pack + (size_t)blockIdx.x * 36 * 64 + lane;
+    const float* src = WhhT + 64 * m + 16 * wave + lcol;
+    for (int ks = 0; ks < 8; ++ks) {
+        Frag16 f0, f1, f2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(src[(size_t)(32 * ks + 8 * lhi + j) * 1024], f0.s[j], f1.s[j], f2.s[j]);
+        dst[(ks * 3 + 0) * 64] = f0.q; dst[(ks * 3 + 1) * 64] = f1.q; dst[(ks * 3 + 2) * 64] = f2.q;
+    }
+    const float* srl = WoutT + 32 * m + 16 * ltile + lcol;
+    for (int ks = 0; ks < 4; ++ks) {
+        Frag16 f0, f1, f2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(srl[(size_t)(32 * (4 * lhalf + ks) + 8 * lhi + j) * 512], f0.s[j], f1.s[j], f2.s[j]);
+        dst[(24 + ks * 3 + 0) * 64] = f0.q; dst[(24 + ks * 3 + 1) * 64] = f1.q; dst[(24 + ks * 3 + 2) * 64] = f2.q;
+    }
+}
+
 // two runs at once: both tasks of a thread in flight together (one L2 round trip instead of two)
 __device__ __forceinline__ void load_run64x2(const u64_t* s0, const u64_t* s1, u32x4_t (&g)[8]) {
     asm volatile(
@@ -128,25 +153,14 @@ __global__ __launch_bounds__(G16NT, 2) void decode_group16_kernel(GroupParams p)
     const int unit = 16 * m + 4 * wave + uq;                 // ... and its hidden unit
     const int ltile = wave & 1, lhalf = wave >> 1;           // logits: column tile, half of the reduction
 
-    // ---- weights -> bf16 pieces in B-operand layout, once
+    // ---- the member's weights, pre-split in B-operand layout by pack16_kernel: 36 coalesced 16-byte loads per lane
     bf16x8_t wg[24], wl[12];                                 // [k-step][piece]
     {
-        const float* src = w.WhhT[0] + 64 * m + 16 * wave + lcol;
+        const u32x4_t* pk = static_cast<const u32x4_t*>(w.wpack16) + (size_t)(m * 4 + wave) * 36 * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            Frag16 f0, f1, f2;
+        for (int i = 0; i < 24; ++i) { Frag16 f; f.q = pk[i * 64]; wg[i] = f.v; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) split3(src[(size_t)(32 * ks + 8 * lhi + j) * G], f0.s[j], f1.s[j], f2.s[j]);
-            wg[ks * 3 + 0] = f0.v; wg[ks * 3 + 1] = f1.v; wg[ks * 3 + 2] = f2.v;
-        }
-        const float* srl = w.WoutT + 32 * m + 16 * ltile + lcol;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            Frag16 f0, f1, f2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) split3(srl[(size_t)(32 * (4 * lhalf + ks) + 8 * lhi + j) * 512], f0.s[j], f1.s[j], f2.s[j]);
-            wl[ks * 3 + 0] = f0.v; wl[ks * 3 + 1] = f1.v; wl[ks * 3 + 2] = f2.v;
-        }
+        for (int i = 0; i < 12; ++i) { Frag16 f; f.q = pk[(24 + i) * 64]; wl[i] = f.v; }
     }
     for (int idx = tid; idx < 2 * 3 * G16_HP_PIECE / 2; idx += G16NT) reinterpret_cast<unsigned*>(hp)[idx] = 0u;   // h(-1) = 0
     if (tid < 32) redk[tid] = 0;
