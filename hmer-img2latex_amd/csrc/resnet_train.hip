@@ -37,7 +37,10 @@ __device__ __forceinline__ void store8(float* __restrict__ p, const float (&v)[8
 }
 
 // Per-channel partial sums over a slab of rows.  Thread = (row lane r of 256 / CG, channel group of 8 channels);
-// MODE 0: (sum z, sum z^2); MODE 1: (sum g, sum g * xhat) with g = dy masked by y > 0.
+// backward (MODE 1): (sum g, sum g * xhat) with g = dy masked by y > 0.  The forward statistics have their own kernel
+// below: (sum d, sum d^2) with d = z - c, c = the channel's value in ROW 0 of the matrix -- a shift of the order of the mean,
+// so that the variance comes out of ONE pass without the cancellation of sum z^2 / M - mean^2 (r04 first used a second
+// pass over z - mean: two more launches per unit).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z, const float* __restrict__ dy,
                                                          const float* __restrict__ y, const float* __restrict__ mean,
@@ -63,10 +66,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
             for (long r = r0 + rl; r < r1; r += lanes) {
                 float zv[8];
                 load8(z + r * C + cg * 8, zv);
-                if (MODE == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { s0[j] += zv[j]; s1[j] += zv[j] * zv[j]; }
-                } else {
+                {
                     float g[8];
                     load8(dy + r * C + cg * 8, g);
                     if (y) {
@@ -96,9 +96,51 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
+// The forward statistics' partial sums (sum d, sum d^2 with d = z - row 0, see above) accumulated and stored in DOUBLE: the
+// kernel is bound by reading z once, the fp64 adds are free, and the one-pass variance then keeps ~1e-7 whatever the shift.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, long M, int C, double* __restrict__ part) {
+    __shared__ double red[2][256][8];
+    const int groups = C / 8;
+    const int cg_per_pass = groups < 256 ? groups : 256;
+    const int lanes = 256 / cg_per_pass;
+    const int tid = threadIdx.x;
+    const int cgl = tid % cg_per_pass, rl = tid / cg_per_pass;
+    const long r0 = (long)blockIdx.x * SLAB_ROWS, r1 = r0 + SLAB_ROWS < M ? r0 + SLAB_ROWS : M;
+    for (int cg0 = 0; cg0 < groups; cg0 += cg_per_pass) {
+        const int cg = cg0 + cgl;
+        double s0[8], s1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.0;
+        if (cg < groups && rl < lanes) {
+            float c0[8];
+            load8(z + cg * 8, c0);                                // the shift: row 0
+            for (long r = r0 + rl; r < r1; r += lanes) {
+                float zv[8];
+                load8(z + r * C + cg * 8, zv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const double d = (double)(zv[j] - c0[j]); s0[j] += d; s1[j] += d * d; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][tid][j] = s0[j]; red[1][tid][j] = s1[j]; }
+        __syncthreads();
+        if (rl == 0 && cg < groups) {                            // lanes added in lane order: deterministic
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                double a = 0.0, b = 0.0;
+                for (int l = 0; l < lanes; ++l) { a += red[0][l * cg_per_pass + cgl][j]; b += red[1][l * cg_per_pass + cgl][j]; }
+                part[((size_t)blockIdx.x * 2 + 0) * C + cg * 8 + j] = a;
+                part[((size_t)blockIdx.x * 2 + 1) * C + cg * 8 + j] = b;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // sums of the slab partials of 32 channels per workgroup: thread = (channel c = tid & 31, slab lane tid >> 5), slabs
 // lane, lane + 8, ... added in double, the 8 lane sums in lane order (deterministic)
-__device__ __forceinline__ void slab_sums(const float* __restrict__ part, int slabs, int C, int c, double (&red)[2][8][32],
+template <typename T>
+__device__ __forceinline__ void slab_sums(const T* __restrict__ part, int slabs, int C, int c, double (&red)[2][8][32],
                                           double& s, double& q) {
     const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
     double a = 0.0, b = 0.0;
@@ -112,77 +154,26 @@ __device__ __forceinline__ void slab_sums(const float* __restrict__ part, int sl
         for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
 }
 
-// forward finalize, pass 1: the mean (the variance comes from a SECOND pass over z - mean: sum z^2 / M - mean^2 in fp32
-// slab sums loses the variance of a channel whose |mean| is large against its spread)
-__global__ __launch_bounds__(256) void bn_mean_final_kernel(const float* __restrict__ part, int slabs, long M, int C,
-                                                            float* __restrict__ mean) {
-    __shared__ double red[2][8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    double s, q;
-    slab_sums(part, slabs, C, c, red, s, q);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
-    mean[c] = (float)(s / (double)M);
-}
-
-// pass 2: (sum (z - mean), sum (z - mean)^2) per slab
-__global__ __launch_bounds__(256) void bn_centered_partial_kernel(const float* __restrict__ z, const float* __restrict__ mean,
-                                                                  long M, int C, float* __restrict__ part) {
-    __shared__ float red[2][256][8];
-    const int groups = C / 8;
-    const int cg_per_pass = groups < 256 ? groups : 256;
-    const int lanes = 256 / cg_per_pass;
-    const int tid = threadIdx.x;
-    const int cgl = tid % cg_per_pass, rl = tid / cg_per_pass;
-    const long r0 = (long)blockIdx.x * SLAB_ROWS, r1 = r0 + SLAB_ROWS < M ? r0 + SLAB_ROWS : M;
-    for (int cg0 = 0; cg0 < groups; cg0 += cg_per_pass) {
-        const int cg = cg0 + cgl;
-        float s0[8], s1[8], mu[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s0[j] = s1[j] = mu[j] = 0.f;
-        if (cg < groups && rl < lanes) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mu[j] = mean[cg * 8 + j];
-            for (long r = r0 + rl; r < r1; r += lanes) {
-                float zv[8];
-                load8(z + r * C + cg * 8, zv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = zv[j] - mu[j]; s0[j] += d; s1[j] += d * d; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { red[0][tid][j] = s0[j]; red[1][tid][j] = s1[j]; }
-        __syncthreads();
-        if (rl == 0 && cg < groups) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float a = 0.f, b = 0.f;
-                for (int l = 0; l < lanes; ++l) { a += red[0][l * cg_per_pass + cgl][j]; b += red[1][l * cg_per_pass + cgl][j]; }
-                part[((size_t)blockIdx.x * 2 + 0) * C + cg * 8 + j] = a;
-                part[((size_t)blockIdx.x * 2 + 1) * C + cg * 8 + j] = b;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// pass 2 finalize: biased variance = sum d^2 / M - (sum d / M)^2 (the second term is the rounding of the fp32 mean),
+// forward finalize: mean = c + sum d / M, biased variance = sum d^2 / M - (sum d / M)^2 (slab sums combined in double),
 // invstd, running statistics (nn.BatchNorm2d: momentum update with the UNBIASED variance)
-__global__ __launch_bounds__(256) void bn_var_final_kernel(const float* __restrict__ part, int slabs, long M, int C, float eps,
-                                                           float momentum, const float* __restrict__ mean,
-                                                           float* __restrict__ invstd, float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var) {
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, const float* __restrict__ z_row0,
+                                                             int slabs, long M, int C, float eps, float momentum,
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
     __shared__ double red[2][8][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     double s, q;
     slab_sums(part, slabs, C, c, red, s, q);
     if ((threadIdx.x >> 5) != 0 || c >= C) return;
     const double dm = s / (double)M;
+    const double mu = (double)z_row0[c] + dm;
     double var = q / (double)M - dm * dm;
     if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
         const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * ((double)mean[c] + dm));
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
 }
@@ -481,8 +472,10 @@ extern "C" int i2l_conv_f32_bwd(const float* x, int x_kind, const float* w, cons
     if (!c.direct) {
         if (dw) {
             float* cimg = reinterpret_cast<float*>(p);
-            const int rc = launch_im2col(x, x_kind, B, H, W, Cin, kh, kw, stride, pad, c.Ho, c.Wo, cimg, s);
-            if (rc != I2L_OK) return rc;
+            if (!(flags & I2L_FLAG_CONV_COL_READY)) {        // else: i2l_conv_f32_fwd left it at the head of this workspace
+                const int rc = launch_im2col(x, x_kind, B, H, W, Cin, kh, kw, stride, pad, c.Ho, c.Wo, cimg, s);
+                if (rc != I2L_OK) return rc;
+            }
             col = cimg;
         }
         p += i2l_align((size_t)M * Kc * sizeof(float));
@@ -525,7 +518,7 @@ extern "C" int i2l_conv_f32_bwd(const float* x, int x_kind, const float* w, cons
 extern "C" size_t i2l_bn_train_workspace_bytes(int64_t M, int C) {
     if (M <= 0 || C <= 0) return 0;
     const size_t slabs = (size_t)((M + SLAB_ROWS - 1) / SLAB_ROWS);
-    return i2l_align(slabs * 2 * (size_t)C * sizeof(float)) + i2l_align(2 * (size_t)C * sizeof(float));
+    return i2l_align(slabs * 2 * (size_t)C * sizeof(double)) + i2l_align(2 * (size_t)C * sizeof(float));   // fwd: double partials
 }
 
 extern "C" int i2l_bn_train_fwd_f32(const float* z, const float* residual, const float* gamma, const float* beta,
@@ -538,14 +531,10 @@ extern "C" int i2l_bn_train_fwd_f32(const float* z, const float* residual, const
     if (!workspace || workspace_bytes < i2l_bn_train_workspace_bytes(M, C)) return I2L_ERR_WORKSPACE;
     hipStream_t s = i2l_s(stream);
     const int slabs = (int)((M + SLAB_ROWS - 1) / SLAB_ROWS);
-    float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(slabs), dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, (long)M, C, part);
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(slabs), dim3(256), 0, s, z, (long)M, C, part);
     I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_mean_final_kernel, dim3(i2l_cdiv(C, 32)), dim3(256), 0, s, part, slabs, (long)M, C, save_mean);
-    I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_centered_partial_kernel, dim3(slabs), dim3(256), 0, s, z, save_mean, (long)M, C, part);
-    I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_var_final_kernel, dim3(i2l_cdiv(C, 32)), dim3(256), 0, s, part, slabs, (long)M, C, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(i2l_cdiv(C, 32)), dim3(256), 0, s, part, z, slabs, (long)M, C, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var);
     I2L_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 0, s, z, residual, gamma, beta, save_mean,

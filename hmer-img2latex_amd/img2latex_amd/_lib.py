@@ -25,6 +25,7 @@ FLAG_EXACT_FP32, FLAG_NO_GROUP, FLAG_RESNET_NO_RING, FLAG_RESNET_IM2COL_STEM = 0
 FLAG_WEIGHTS_PACKED = 0x10          # conv forward: the workspace still holds the packed filters of these weights
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
 FLAG_CONV_NO_SPARSE_WGRAD = 0x4000   # first conv block's weight gradient by the implicit-im2col GEMM (A/B)
+FLAG_CONV_COL_READY = 0x10000        # i2l_conv_f32_bwd: the workspace still holds the forward call's column image
 FLAG_DECODE_GROUP16 = 0x8000         # greedy decode: 16 members x 16 rows per group, per-step products on the matrix cores (split-bf16 MFMA)
 FLAG_DECODE_GROUP8 = 0x1000          # greedy decode: 8 members x 8 rows per group (co-resident with a conv workgroup)
 FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks of the grouped kernels

@@ -210,8 +210,13 @@ class ResNetEncoder(nn.Module):
         dev, co = x.device, conv.out_channels
         kind = 2 if nchw else 1
         z = torch.empty((B, Ho, Wo, co), dtype=torch.float32, device=dev)
-        nbytes = L.i2l_conv_f32_workspace_bytes(kind, B, H, W, Cin, co, k, k, s, pd, 0)
-        ws = self._workspace(nbytes, dev)
+        # a unit whose weight gradient will be asked for keeps its OWN workspace on the tape: the fp32 column image the
+        # forward GEMM read is what the weight-gradient GEMM reads again (I2L_FLAG_CONV_COL_READY: no second im2col)
+        direct = k == 1 and s == 1 and pd == 0 and not nchw
+        keep_col = tape is not None and conv.weight.requires_grad and not direct
+        nbytes = L.i2l_conv_f32_workspace_bytes(kind, B, H, W, Cin, co, k, k, s, pd, 1 if keep_col and not nchw else 0)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if keep_col else self._workspace(nbytes, dev)
+        conv_ws = ws if keep_col else None
         _lib.check(L.i2l_conv_f32_fwd(x.data_ptr(), kind, conv.weight.detach().data_ptr(), z.data_ptr(), B, H, W, Cin, co,
                                       k, k, s, pd, ws.data_ptr(), nbytes, self.kernel_flags & _lib.FLAG_EXACT_FP32,
                                       _lib.stream_ptr()), "conv_f32_fwd")
@@ -237,7 +242,7 @@ class ResNetEncoder(nn.Module):
                 torch.autograd.graph.increment_version(t)
         if tape is not None:
             tape.append(dict(conv=conv, bn=bn, x=x, in_shape=shape, nchw=nchw, z=z, y=y, relu=relu, mean=mean,
-                             invstd=invstd, out_shape=(B, Ho, Wo, co), residual=residual))
+                             invstd=invstd, out_shape=(B, Ho, Wo, co), residual=residual, conv_ws=conv_ws))
         return y, (B, Ho, Wo, co)
 
     def _trunk_train(self, x: torch.Tensor, tape) -> torch.Tensor:
@@ -298,10 +303,16 @@ class ResNetEncoder(nn.Module):
         kind = 2 if u["nchw"] else 1
         dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev) if need_dx else None
         nbytes = L.i2l_conv_f32_workspace_bytes(kind, B, H, W, Cin, co, k, k, s, pd, 1 if need_dx else 0)
-        ws = self._workspace(nbytes, dev)
+        flags = self.kernel_flags & _lib.FLAG_EXACT_FP32
+        ws = u.get("conv_ws")
+        if ws is not None and want_dw and ws.numel() >= nbytes:
+            flags |= _lib.FLAG_CONV_COL_READY            # the forward call's column image is still at the head of this workspace
+            u["conv_ws"] = None                          # ... and after this call it no longer is (dcol / GEMM slabs behind it are)
+        else:
+            ws = self._workspace(nbytes, dev)
         _lib.check(L.i2l_conv_f32_bwd(u["x"].data_ptr(), kind, conv.weight.detach().data_ptr(), dz.data_ptr(), _lib.ptr(dx),
                                       grads[name + ".weight"].data_ptr() if want_dw else None, B, H, W, Cin, co, k, k, s, pd,
-                                      ws.data_ptr(), nbytes, self.kernel_flags & _lib.FLAG_EXACT_FP32, _lib.stream_ptr()),
+                                      ws.data_ptr(), nbytes, flags, _lib.stream_ptr()),
                    "conv_f32_bwd")
         return dx
 

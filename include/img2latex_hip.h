@@ -74,6 +74,9 @@ typedef void* i2l_stream_t;
                                           v_mfma_f32_16x16x32_bf16 bursts (fp32-grade: 3 bf16 pieces per operand, 6 partial
                                           products) -- ~250 registers and 49 KB of LDS per CU, and a burst that conv waves on
                                           the same CU barely stretch; same ids up to fp32 near-ties.  Wins over _GROUP8 if both set */
+#define I2L_FLAG_CONV_COL_READY 0x10000 /* i2l_conv_f32_bwd: the workspace is the one the matching i2l_conv_f32_fwd call used and
+                                          nothing has written to it since, so its head still holds the column image of x: skip
+                                          the im2col launch (the caller keeps one workspace per unit on its tape)               */
 #define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
                                           implicit-im2col GEMM instead of the sparse first-block kernel (A/B, tests)   */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
@@ -194,8 +197,9 @@ int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H, int W, in
  * batch of the stem); w (Cout,Cin,kh,kw) fp32 as stored by nn.Conv2d; z / dz (B,Ho,Wo,Cout) NHWC fp32.
  *   fwd: z = conv(x, w)
  *   bwd: dw (Cout,Cin,kh,kw) = d/dw, dx (B,H,W,Cin) NHWC fp32 = d/dx; either may be NULL (dx needs x_kind 1).
- * The workspace holds the fp32 column image (none for 1x1 / stride 1), for dx its gradient, and the GEMM slabs;
- * backward_dx != 0 sizes it for a call with dx. */
+ * The workspace holds the fp32 column image (none for 1x1 / stride 1) at its head, for dx its gradient, and the GEMM slabs;
+ * backward_dx != 0 sizes it for a call with dx (a workspace of that size also serves the forward call, and handing the
+ * SAME one to the backward call with I2L_FLAG_CONV_COL_READY saves the second im2col). */
 size_t i2l_conv_f32_workspace_bytes(int x_kind, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
                                     int pad, int backward_dx);
 int i2l_conv_f32_fwd(const float* x, int x_kind, const float* w, float* z, int B, int H, int W, int Cin, int Cout,
@@ -205,8 +209,9 @@ int i2l_conv_f32_bwd(const float* x, int x_kind, const float* w, const float* dz
                      int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace,
                      size_t workspace_bytes, int flags, i2l_stream_t stream);
 /* nn.BatchNorm2d in training mode on a row-major (M, C) fp32 matrix z, C % 8 == 0 (+ residual add, + ReLU):
- *   fwd: mean, then the biased variance from a second pass over z - mean (both combined in double); running_* (may both
- *        be NULL) <- (1 - momentum) * running + momentum * (mean, UNBIASED variance);
+ *   fwd: mean and biased variance from ONE pass over z - c (c = row 0 of z: a shift of the order of the mean, so that no
+ *        digits cancel; slab sums combined in double); running_* (may both be NULL) <- (1 - momentum) * running +
+ *        momentum * (mean, UNBIASED variance);
  *        y = act(gamma * (z - mean) * invstd + beta + residual); save_mean / save_invstd (C)
  *   bwd: g = dy masked by y_relu > 0 (y_relu NULL: no ReLU);  dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));
  *        dgamma = sum g * xhat, dbeta = sum g (either may be NULL); dres (may be NULL) = g (or += g): the gradient of

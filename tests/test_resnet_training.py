@@ -101,8 +101,13 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
         ref = _unit_reference(u)
         zf, yf = u["z"], u["y"]
         worst["z"] = max(worst["z"], _rel(zf, ref["z"]))
-        worst["stat"] = max(worst["stat"], _rel(u["mean"], zf.double().mean(dim=(0, 1, 2))),
-                            _rel(1.0 / u["invstd"].double() ** 2 - u["bn"].eps, zf.double().var(dim=(0, 1, 2), unbiased=False)))
+        # statistics as the normalisation sees them, per channel: the mean's error in units of the channel's spread, the
+        # variance's error relative to that variance (sharper than "relative to the largest channel", and well-posed for the
+        # stem, whose means are ~1e-3 of its spreads)
+        m_ref, v_ref = zf.double().mean(dim=(0, 1, 2)), zf.double().var(dim=(0, 1, 2), unbiased=False)
+        e_mean = float(((u["mean"].double() - m_ref).abs() / (v_ref + u["bn"].eps).sqrt()).max())
+        e_var = float((((1.0 / u["invstd"].double() ** 2 - u["bn"].eps) - v_ref).abs() / (v_ref + u["bn"].eps)).max())
+        worst["stat"] = max(worst["stat"], e_mean, e_var)
         # y from the HIP z / statistics themselves: the elementwise formula, evaluated in another order
         yn = (zf - u["mean"]) * u["invstd"] * u["bn"].weight.detach() + u["bn"].bias.detach()
         yn = yn + (u["residual"] if u["residual"] is not None else 0.0)
@@ -116,8 +121,8 @@ def test_resnet_training_forward_backward_vs_oracle(name, freeze, B, H, W):
         worst["run"] = max(worst["run"], _rel(u["bn"].running_mean, rm), _rel(u["bn"].running_var, rv))
         assert int(u["bn"].num_batches_tracked) == 1
     for k, v in worst.items():
-        record(f"{tag} train forward, worst unit: {k} vs independent fp32 [rel to max]", v)
-    assert worst["stat"] <= 2e-6 and worst["run"] <= 2e-6, worst          # r03 (statistics of a bf16 z): 1e-4
+        record(f"{tag} train forward, worst unit: {k} vs independent fp32 [rel to max; stat: per channel, mean in units of std]", v)
+    assert worst["stat"] <= 1e-6 and worst["run"] <= 2e-6, worst          # r03 (statistics of a bf16 z): 1e-4 of the maximum
     assert worst["z"] <= 2e-5 and worst["y"] <= 1e-4, worst               # r03 (bf16 tape): 1.5e-2 / 5e-2
     # ---- (2) every unit of the backward: gradients of the SAME upstream gradient through an fp32 autograd of the unit
     first_trainable = min(i for i, u in enumerate(tape["units"])
