@@ -11,7 +11,7 @@ model = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), s
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=42, out_scale=8.0, enc_scale=16.0).items()})
 model = model.to(dev).eval()
 x = torch.from_numpy(synth.make_images(256, cfg, seed=1234)).to(dev)
-pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8, decode_priority=-1, hold_encoder=(os.environ['HOLD'] != '0' if 'HOLD' in os.environ else None))   # HOLD=0: no residency dependency (A/B)
+pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=(_lib.FLAG_DECODE_GROUP8 if os.environ.get("MEMBERS") == "8" else _lib.FLAG_DECODE_GROUP16), decode_priority=-1, hold_encoder=(os.environ['HOLD'] != '0' if 'HOLD' in os.environ else None))   # HOLD=0: no residency dependency (A/B)
 def run(n, stamps=None):
     t0 = time.perf_counter()
     for i in range(n):

@@ -89,6 +89,10 @@ def mfma_table(sub, dst_name):
                 "mfma_util_time_based,gui_window_exclusive\n")
         for r in sorted(rows, key=lambda r: -r[2]):
             util_t = r[3] / (1024.0 * r[2] * 1e3 * clk_ref)
+            if sub == "mfma":                       # the headline's kernels: matrix-pipe busy fraction per bench stage (bench.py reads it)
+                for frag, (stage, _) in STAGE.items():
+                    if frag in r[0]:
+                        out.setdefault("_mfma_busy", {})[stage] = round(util_t, 4)
             f.write(f"\"{r[0]}\",{r[1]},{r[2]:.1f},{r[3]:.0f},{r[4]:.0f},{r[5]:.4f},{r[6]:.3f},{util_t:.4f},"
                     f"{'yes' if r[6] <= 2.45 else 'NO'}\n")
     print(dst_name, f"(clock reference {clk_ref:.2f} GHz)")
