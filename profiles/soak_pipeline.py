@@ -11,12 +11,13 @@ from img2latex_amd.model import Seq2SeqModel
 from img2latex_amd.pipeline import GreedyPipeline
 dev = torch.device("cuda:0")
 cfg = synth.model_config()
+FLAG = _lib.FLAG_DECODE_GROUP8 if os.environ.get("MEMBERS") == "8" else _lib.FLAG_DECODE_GROUP16    # r04 default: the matrix-core decode
 
 def soak(model, name, n, enc_streams):
     sets = [torch.from_numpy(synth.make_images(256, cfg, seed=s)).to(dev) for s in (1234, 77, 78)]
     with torch.no_grad():
-        want = [_lib.check_ids(model.greedy_ids(model.encoder(x), synth.START, synth.END, 150, flags=_lib.FLAG_DECODE_GROUP8)[0].cpu()).numpy().copy() for x in sets]
-    pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=_lib.FLAG_DECODE_GROUP8,
+        want = [_lib.check_ids(model.greedy_ids(model.encoder(x), synth.START, synth.END, 150, flags=FLAG)[0].cpu()).numpy().copy() for x in sets]
+    pipe = GreedyPipeline(model, synth.START, synth.END, 150, rows_per_workgroup=0, decode_flags=FLAG,
                           decode_priority=-1, encoder_streams=enc_streams)
     order, got_bad, k = [], 0, 0
     torch.cuda.synchronize(); t0 = time.perf_counter()

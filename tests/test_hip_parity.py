@@ -878,14 +878,21 @@ def test_agent_scope_exchange_gives_identical_results():
     with torch.no_grad():
         enc = m.encoder(x)
         fast, _ = m.greedy_ids(enc, START, END, 150)
+        fast8, _ = m.greedy_ids(enc, START, END, 150, flags=_lib.FLAG_DECODE_GROUP8)
+        fast16, _ = m.greedy_ids(enc, START, END, 150, flags=_lib.FLAG_DECODE_GROUP16)
         fast_b, fast_s = m.beam_search_batch(enc[:37].contiguous(), START, END, 48, 5, return_scores=True)
         m.decoder.kernel_flags = _lib.FLAG_AGENT_SCOPE_EXCHANGE
         try:
             slow, _ = m.greedy_ids(enc, START, END, 150)
+            slow8, _ = m.greedy_ids(enc, START, END, 150, flags=_lib.FLAG_DECODE_GROUP8)
+            slow16, _ = m.greedy_ids(enc, START, END, 150, flags=_lib.FLAG_DECODE_GROUP16)
+            assert m.decoder.group_status()["groups_on_one_xcd"] == 0           # the conformant flavour never claims the L2-local one
             slow_b, slow_s = m.beam_search_batch(enc[:37].contiguous(), START, END, 48, 5, return_scores=True)
         finally:
             m.decoder.kernel_flags = 0
     assert torch.equal(_lib.check_ids(slow.cpu()), _lib.check_ids(fast.cpu()))
+    assert torch.equal(_lib.check_ids(slow8.cpu()), _lib.check_ids(fast8.cpu()))
+    assert torch.equal(_lib.check_ids(slow16.cpu()), _lib.check_ids(fast16.cpu()))
     assert slow_b == fast_b and slow_s == fast_s
     cfg3 = synth.model_config(dropout=0.0)
     np_sd = synth.make_state_dict(cfg3, seed=42)
