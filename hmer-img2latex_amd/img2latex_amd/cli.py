@@ -133,14 +133,20 @@ def train(config_path: str = "img2latex/configs/config.yaml", experiment_name: s
     os.makedirs(ck_dir, exist_ok=True)
     last, path = None, None
     is_resnet = config["model"]["name"] == "resnet_lstm"
+    accum = max(1, int(tcfg.get("accumulation_steps", 1)))                  # trainer.py:86-88 (the shipped config: 4)
     for epoch in range(start_epoch + 1, max_epochs + 1):                    # `epoch` = trainer.py's current_epoch + 1
         batches = _synthetic_batches(config, synthetic_steps, tokenizer.vocab_size, seed) if loaders is None else loaders["train"]
-        for batch in batches:
+        it = iter(batches)
+        batch, batch_idx = next(it, None), 0
+        while batch is not None:
+            nxt = next(it, None)                                            # one batch of look-ahead: "is this the last one?" (:374)
             images = batch["images"].to(dev)                                # data/utils.py:113-135 prepare_batch
             if is_resnet and images.shape[1] == 1:
                 images = D.batch_convert_for_resnet(images)
-            last = ts.step(images, batch["formulas"].to(dev))
-            step += 1
+            update = (batch_idx + 1) % accum == 0 or nxt is None
+            last = ts.micro_step(images, batch["formulas"].to(dev), accum, update)
+            step += 1                                                       # the reference's global_step counts batches (:399)
+            batch, batch_idx = nxt, batch_idx + 1
         loss = float(last["loss"]) if last is not None else float("nan")
         path = os.path.join(ck_dir, f"checkpoint_epoch_{epoch}_step_{step}.pt")
         save_checkpoint(path, model, tokenizer, config, epoch=epoch, step=step, metrics={"loss": loss},

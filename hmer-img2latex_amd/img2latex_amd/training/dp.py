@@ -60,8 +60,8 @@ class OverlappedAllReduce:
         buffer is being reduced in place.  A second start_early() without it -- a forward_backward() repeated after an
         exception, or a caller only inspecting gradients -- first waits for the pending piece, so that the next
         backward does not overwrite memory a collective is still reading; the buffer then holds the REDUCED early
-        gradients of the abandoned step, which the new backward overwrites (gradient accumulation across several
-        forward_backward() calls is not supported under data parallelism)."""
+        gradients of the abandoned step, which the new backward overwrites.  Gradient accumulation (trainer.py:345-383) is
+        TrainStep.micro_step: it switches the early piece off and reduces the accumulated buffer once, at the update."""
         if self._work is not None:
             self._work.wait()
             self._work = None

@@ -80,6 +80,8 @@ class TrainStep:
         self.side_wgrad = bool(side_wgrad)
         self._lanes = _lib.Lanes(dev, 2) if self.side_wgrad else None
         self._side_keep = []          # buffers the side lanes' kernels still read; released after the join
+        self._accum = None            # gradient accumulation (micro_step): sum over micro-batches of grad(mean loss) / k
+        self._micro = 0               # micro-batches accumulated since the last update
         self._ar_stream = None        # helper stream the early all-reduce piece is issued from (data parallel only)
         self._reducer = OverlappedAllReduce(self.flat_grads, self.n_early, self.group)
         L = _lib.lib()
@@ -98,7 +100,7 @@ class TrainStep:
         B, T = tokens_in.shape
         # one dropout stream per (seed, optimizer step, data-parallel rank): the kernels hash the LOCAL element index,
         # so without the rank every replica would reuse rank 0's masks for its own rows
-        self.step_seed = ((self.seed * 1000003 + self.step_count) * 4099 + self.rank) & 0x3FFFFFFFFFFFFFFF
+        self.step_seed = ((self.seed * 1000003 + self.step_count) * 4099 + self.rank + 7919 * self._micro) & 0x3FFFFFFFFFFFFFFF
         enc, enc_state = encoder_train_forward(model.encoder, images)
         logits, dec_state = decoder_train_forward(model.decoder, enc, tokens_in, self.step_seed)
         V = logits.shape[-1]
@@ -179,6 +181,45 @@ class TrainStep:
         count = self.flat_grads[self.n + 1]
         return dict(loss=self.flat_grads[self.n] / count.clamp(min=1.0), total_norm=self.stats[0], count=count,
                     skipped=self.stats[3])
+
+    def micro_step(self, images: torch.Tensor, formulas: torch.Tensor, accumulation_steps: int, update: bool) -> Dict[str, torch.Tensor]:
+        """Gradient accumulation, trainer.py:345-383 (the shipped configuration: accumulation_steps 4): every micro-batch
+        contributes the gradient of ITS mean loss divided by ``accumulation_steps`` (``loss = criterion(...) /
+        accumulation_steps; loss.backward()``), and with ``update`` -- every accumulation_steps-th batch or the last one of
+        the epoch, :374 -- the sum is clipped and Adam steps.  Data parallel: a micro-batch's mean is over the GLOBAL
+        micro-batch, so its [loss sum, count] pair is all-reduced at once (8 bytes) and the accumulated gradients once, at
+        the update.  Returns the micro-batch's mean loss (what the reference logs, :386-388) and, after an update,
+        ``total_norm`` / ``skipped``."""
+        import torch.distributed as dist
+        if accumulation_steps < 1:
+            raise ValueError("accumulation_steps must be >= 1")
+        if accumulation_steps == 1 and self._micro == 0 and update:
+            return self.step(images, formulas)
+        self.model.train()
+        overlap, self.overlap_all_reduce = self.overlap_all_reduce, False      # nothing of a micro-batch is reduced early
+        try:
+            self.forward_backward(images, formulas)
+        finally:
+            self.overlap_all_reduce = overlap
+        tail = self.flat_grads[self.n:self.n + 2].clone()                      # [loss sum, count] of this micro-batch
+        if self._reducer._active():
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+        inv = 1.0 / (tail[1].clamp(min=1.0) * float(accumulation_steps))
+        if self._accum is None:
+            self._accum = torch.zeros(self.n, dtype=torch.float32, device=self.flat_grads.device)
+        self._accum.addcmul_(self.flat_grads[:self.n], inv.expand(self.n))
+        self._micro += 1
+        out = dict(loss=tail[0] / tail[1].clamp(min=1.0), count=tail[1])
+        if update:
+            world = dist.get_world_size(self.group) if self._reducer._active() else 1
+            self.flat_grads[:self.n].copy_(self._accum)
+            self.flat_grads[self.n] = out["loss"] / world                      # the slots the fused kernel divides by: the sum
+            self.flat_grads[self.n + 1] = 1.0 / world                          # over ranks of the count slot is exactly 1
+            self._accum.zero_()
+            self._micro = 0
+            self.apply()
+            out.update(total_norm=self.stats[0], skipped=self.stats[3])
+        return out
 
     def applied_steps(self) -> int:
         """Optimizer steps actually applied (host sync): step_count minus the skipped, non-finite ones.  Called at

@@ -576,3 +576,45 @@ def test_reference_trainer_loop_over_the_dropin_model(name, amp):
         m.decoder._ws_by_stream.clear()
         b = m(images_, formulas)
     assert torch.equal(a, b)
+
+
+def test_gradient_accumulation_vs_oracle():
+    """TrainStep.micro_step = the reference's accumulation branch (trainer.py:345-383; the shipped config has
+    accumulation_steps: 4): every micro-batch adds the gradient of ITS mean loss / k, the update comes every k-th batch or
+    at the last one of the epoch.  Three micro-batches with k = 2 -- one full group, one partial -- against the oracle:
+    per-micro-batch gradients by autograd, summed / k, clipped by the global norm, Adam; parameters within 1e-5 after
+    each of the two updates, and nothing moves between updates."""
+    from img2latex_amd.training import TrainStep
+    cfg = synth.model_config(vocab_size=50, embedding_dim=32, hidden_dim=64, lstm_layers=1, attention=False, channels=1,
+                             img_height=16, img_width=32, conv_filters=(4, 8, 16), dropout=0.0)
+    np_sd = synth.make_state_dict(cfg, seed=21)
+    m = Seq2SeqModel("cnn_lstm", cfg["vocab_size"], synth.encoder_params(cfg), synth.decoder_params(cfg))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in np_sd.items()})
+    m = m.to(DEV)
+    ts = TrainStep(m, lr=1e-3, seed=5)
+    sd = O.to_torch_sd(np_sd)
+    state = {}
+    k = 2
+    micro = [(torch.from_numpy(synth.make_images(5 + j, cfg, seed=80 + j)),
+              torch.from_numpy(synth.make_formulas(5 + j, 12, cfg["vocab_size"], seed=90 + j, min_len=4))) for j in range(3)]
+    acc = None
+    for j, (x, f) in enumerate(micro):
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        update = (j + 1) % k == 0 or j == len(micro) - 1
+        out = ts.micro_step(x.to(DEV), f.to(DEV), k, update)
+        loss, g = O.loss_and_grads(sd, cfg, x, f)
+        assert abs(float(out["loss"]) - loss) <= 1e-5 * max(1.0, abs(loss))
+        acc = {n: v / k for n, v in g.items()} if acc is None else {n: acc[n] + g[n] / k for n in g}
+        if not update:
+            for n, p in m.named_parameters():
+                assert torch.equal(p.detach(), before[n]), n           # no update inside a group
+            continue
+        total = O.clip_grad_norm(acc, 5.0)
+        with torch.no_grad():
+            O.adam_step(sd, acc, state)
+        acc = None
+        assert abs(float(out["total_norm"]) - float(total)) <= 1e-4 * max(1.0, float(total))
+        worst = max(float((p.detach().cpu() - sd[n]).abs().max()) for n, p in m.named_parameters())
+        record(f"gradient accumulation k={k}, update {ts.step_count}: parameters vs oracle [abs]", worst)
+        assert worst <= 1e-5, worst
+    assert ts.step_count == 2 and ts._micro == 0

@@ -144,7 +144,7 @@ def test_cli_predict_and_train(tmp_path):
     ck = torch.load(PT, map_location="cpu", weights_only=False)
     config = dict(ck["config"])
     config["data"] = {"batch_size": 8, "max_seq_length": 20}
-    config["training"] = dict(config["training"], device="cuda", epochs=1)
+    config["training"] = dict(config["training"], device="cuda", epochs=1, accumulation_steps=1)
     cfg_path = tmp_path / "config.yaml"
     cfg_path.write_text(yaml.safe_dump(config))
     from img2latex_amd import cli
@@ -156,4 +156,10 @@ def test_cli_predict_and_train(tmp_path):
     assert os.path.basename(out["checkpoint"]) == f"checkpoint_epoch_{again['epoch']}_step_{again['step']}.pt"
     assert set(again) == set(ck) and again["optimizer_state_dict"]["state"][0]["step"].item() == 3.0
     assert isinstance(cli.predict(out["checkpoint"], PNG, max_length=10), str)
+    # trainer.py:345-383 through the CLI: accumulation_steps 2 over 3 batches = an update after batch 2 and one at the last batch
+    config["training"]["accumulation_steps"] = 2
+    cfg_path.write_text(yaml.safe_dump(config))
+    out2 = cli.train(str(cfg_path), "cli_test_acc", PT, None, "cuda", 7, synthetic_steps=3, output_dir=str(tmp_path / "outputs"))
+    acc = torch.load(out2["checkpoint"], map_location="cpu", weights_only=False)
+    assert out2["steps"] == 3 and acc["step"] == ck["step"] + 3 and acc["optimizer_state_dict"]["state"][0]["step"].item() == 2.0
     assert cli.main(["train", "--config-path", str(tmp_path / "missing.yaml"), "--synthetic-steps", "1"]) == 1   # cli.py:247-250
