@@ -91,6 +91,33 @@ __global__ __launch_bounds__(MT) void sequence_metrics_kernel(const int32_t* __r
     if (tid < 2 && tla_out) tla_out[(size_t)pair * 2 + tid] = cnt[4 + tid];
 }
 
+// One pass of a four-token window over seq[0..len): cnt[n-1] += (the n-gram at j equals own[0..n)) for n = 1..4; an n-gram
+// at j exists while j + n <= len.  OWN: the sequence is the one position i lives in -- a match at j < i means i is not
+// the first occurrence of its n-gram (each distinct n-gram is counted once, at its first occurrence: metrics.py:136-160).
+template <bool OWN>
+__device__ __forceinline__ void ngram_scan(const int* __restrict__ seq, int len, int i, const int (&own)[4], int (&cnt)[4],
+                                           bool (&first)[4]) {
+    int w0 = len > 0 ? seq[0] : 0, w1 = len > 1 ? seq[1] : 0, w2 = len > 2 ? seq[2] : 0, w3 = len > 3 ? seq[3] : 0;
+    for (int j = 0; j < len; ++j) {
+        const int nx = j + 4 < len ? seq[j + 4] : 0;
+        const bool e1 = w0 == own[0];
+        const bool e2 = e1 && j + 2 <= len && w1 == own[1];
+        const bool e3 = e2 && j + 3 <= len && w2 == own[2];
+        const bool e4 = e3 && j + 4 <= len && w3 == own[3];
+        cnt[0] += e1 ? 1 : 0;
+        cnt[1] += e2 ? 1 : 0;
+        cnt[2] += e3 ? 1 : 0;
+        cnt[3] += e4 ? 1 : 0;
+        if (OWN && j < i) {
+            first[0] = first[0] && !e1;
+            first[1] = first[1] && !e2;
+            first[2] = first[2] && !e3;
+            first[3] = first[3] && !e4;
+        }
+        w0 = w1; w1 = w2; w2 = w3; w3 = nx;
+    }
+}
+
 // The same statistics with the Levenshtein distance from Myers' bit-vector algorithm (block formulation, J. ACM 46(3)
 // 1999; global-distance boundary as in Hyyro 2003) instead of the anti-diagonal table walk: the reference's recurrence
 // (metrics.py:73-81: equal tokens copy the diagonal, otherwise 1 + min of the three neighbours) IS the Levenshtein
@@ -164,29 +191,26 @@ __global__ __launch_bounds__(MT) void sequence_metrics_bp_kernel(const int32_t* 
         if (lane == 0) lev_out[pair] = score;
     } else {
         const int t3 = tid - 64, NT3 = MT - 64;
-        for (int g = 1; g <= max_n; ++g) {
-            const int ng = R - g + 1, nt = C - g + 1;
-            int local = 0;
-            if (ng > 0 && nt > 0) {
-                for (int i = t3; i < ng; i += NT3) {
-                    bool first = true;
-                    int cg = 0, ct = 0;
-                    for (int j = 0; j < ng; ++j) {
-                        bool eq = true;
-                        for (int k = 0; k < g; ++k) eq = eq && a[j + k] == a[i + k];
-                        cg += eq ? 1 : 0;
-                        if (eq && j < i) first = false;
-                    }
-                    for (int j = 0; j < nt; ++j) {
-                        bool eq = true;
-                        for (int k = 0; k < g; ++k) eq = eq && b[j + k] == a[i + k];
-                        ct += eq ? 1 : 0;
-                    }
-                    if (first) local += min(cg, ct);
-                }
-            }
-            if (local) atomicAdd(&cnt[g - 1], local);
+        // clipped n-gram matches for n = 1..4 in ONE pass per sequence: the thread that owns position i keeps its four
+        // tokens in registers and slides a four-token window over the prediction (count of its n-gram; "is i its first
+        // occurrence?") and over the target (count there): one LDS read per window position, where a loop per n with
+        // the n-grams compared out of LDS made 2 n dependent reads (0.26 ms per 256 pairs of 150 tokens, r04)
+        int local[4] = {0, 0, 0, 0};
+        for (int i = t3; i < R; i += NT3) {
+            int ai[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ai[k] = i + k < R ? a[i + k] : 0;
+            int cg[4] = {0, 0, 0, 0}, ct[4] = {0, 0, 0, 0};
+            bool first[4] = {true, true, true, true};
+            ngram_scan<true>(a, R, i, ai, cg, first);
+            ngram_scan<false>(b, C, i, ai, ct, first);
+#pragma unroll
+            for (int g = 1; g <= 4; ++g)            // i < R - g + 1: position i starts an n-gram of the prediction
+                if (g <= max_n && i < R - g + 1 && C - g + 1 > 0 && first[g - 1]) local[g - 1] += min(cg[g - 1], ct[g - 1]);
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (local[g]) atomicAdd(&cnt[g], local[g]);
         const int ml = min(R, C);
         int correct = 0, nonpad = 0;
         for (int i = t3; i < ml; i += NT3) {

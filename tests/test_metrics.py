@@ -160,6 +160,12 @@ def test_bit_vector_levenshtein_block_boundaries(width):
             p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
             assert int(st["lev"][i]) == MO.levenshtein_raw(p, t), (width, alpha, i, pl[i], tl[i])
             assert st["match"][i].tolist() == MO.ngram_matches(p, t, 4), (width, alpha, i)
+        st2 = M.device_sequence_statistics(torch.from_numpy(P).to(dev), torch.from_numpy(pl).to(dev),
+                                           torch.from_numpy(T).to(dev), torch.from_numpy(tl).to(dev), 2, PAD, _max_len=width)
+        for i in range(B):                                       # max_n below 4: the higher orders stay 0
+            p, t = P[i, : pl[i]].tolist(), T[i, : tl[i]].tolist()
+            assert st2["match"][i].tolist()[:2] == MO.ngram_matches(p, t, 2), (width, alpha, i)
+            assert st2["match"][i].tolist()[2:] in ([], [0, 0]), (width, alpha, i)
 
 
 def test_scores_host_helper_is_bit_identical_to_the_python_formulas():
