@@ -400,6 +400,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_bf16_ring_kernel(BfGemm g, int 
     }
 }
 
+#include "resnet_patch.inc.h"
+
 // ------------------------------------------------------------------ fused stem (7x7, stride 2, pad 3, 3 -> 64)
 // conv1 + bn1 + relu straight from the fp32 NCHW images to NHWC bf16: no im2col image in HBM (that image is
 // 420 MB at B=256 and cost 0.6 ms to write and read back).  A workgroup walks 4x32-pixel output tiles, one
@@ -703,7 +705,7 @@ bool stem_shape(int Cin, int Cout, int kh, int kw, int stride, int pad) {
 // that has more tiles than CUs.  With at most one tile per CU only the ring hides latency: 4 stages.
 int ring_depth(int kt, long tiles, int flags) {
     const int forced = (flags >> 8) & 0xF;
-    if (forced >= 2 && forced <= 4) return forced;
+    if (forced >= 2 && forced <= 5) return forced;
     return (tiles <= 256 && kt >= 4) ? 4 : 2;
 }
 template <int NTW, int BK, int NS, bool CONV, bool RES, int OCC = 1>
@@ -728,6 +730,7 @@ int launch_ring2(const BfGemm& g, int nb_n, int total, hipStream_t s) {
 }
 template <int NTW>
 int launch_ring(const BfGemm& g, int depth, int nb_n, int total, hipStream_t s) {
+    if (depth == 5) return launch_ring2<NTW, 32, 4>(g, nb_n, total, s);      // experiment: 32-deep K tiles, 4 stages, same LDS as <64, 2>
     return depth == 4 ? launch_ring2<NTW, 64, 4>(g, nb_n, total, s)
          : depth == 3 ? launch_ring2<NTW, 64, 3>(g, nb_n, total, s) : launch_ring2<NTW, 64, 2>(g, nb_n, total, s);
 }
@@ -835,6 +838,11 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     // the matrix cores: 64-column tiles at THREE workgroups per CU (48 KB of LDS, <= 168 registers) keep more bytes in flight
     const bool short_k = direct && Kp <= 256 && !((flags >> 8) & 0xF) && (long)i2l_cdiv((int)M, GM) * i2l_cdiv(Cout, 64) >= 1024;
     const int gn = (Cout <= 64 || short_k) ? 64 : 128;     // narrow tile for the 64-channel layers (no wasted MFMAs)
+    if (implicit && kh == 3 && kw == 3 && stride == 1 && pad == 1 && !(flags & (I2L_FLAG_RESNET_NO_RING | I2L_FLAG_RESNET_NO_PATCH))) {
+        // input patch staged in LDS, filters through the ring; the tile shape is picked for balance over the CUs
+        const PatchPlan pp = patch_plan((long)M, H, W, Cin, Cout, 256, (flags >> 20) & 0xF);
+        if (pp.shape >= 0) return launch_patch(g, pp, s);
+    }
     if (!(flags & I2L_FLAG_RESNET_NO_RING) && (direct || implicit) && Kp % 64 == 0) {
         const int nb_n = i2l_cdiv(Cout, gn), nb_m = i2l_cdiv((int)M, GM);
         const long total = (long)nb_n * nb_m;

@@ -26,6 +26,7 @@ FLAG_WEIGHTS_PACKED = 0x10          # conv forward: the workspace still holds th
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
 FLAG_CONV_NO_SPARSE_WGRAD = 0x4000   # first conv block's weight gradient by the implicit-im2col GEMM (A/B)
 FLAG_CONV_COL_READY = 0x10000        # i2l_conv_f32_bwd: the workspace still holds the forward call's column image
+FLAG_RESNET_NO_PATCH = 0x20000       # i2l_conv_bn_act_bf16_fwd: 3x3 convs on the implicit-GEMM ring kernel (A/B switch)
 FLAG_DECODE_GROUP16 = 0x8000         # greedy decode: 16 members x 16 rows per group, per-step products on the matrix cores (split-bf16 MFMA)
 FLAG_DECODE_GROUP8 = 0x1000          # greedy decode: 8 members x 8 rows per group (co-resident with a conv workgroup)
 FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks of the grouped kernels
@@ -33,6 +34,11 @@ FLAG_TEST_SHORT_TIMEOUT, FLAG_TEST_DROP_MEMBER = 0x40, 0x80       # test hooks o
 
 def flag_resnet_ring_depth(n: int) -> int:
     return (int(n) & 0xF) << 8
+
+
+def flag_resnet_patch_shape(n: int) -> int:
+    """I2L_FLAG_RESNET_PATCH_SHAPE(n): force tile shape n (1..5) of the 3x3 patch kernel; 0 = picked for balance."""
+    return (int(n) & 0xF) << 20
 
 
 class DecoderWeights(ctypes.Structure):

@@ -77,9 +77,13 @@ typedef void* i2l_stream_t;
 #define I2L_FLAG_CONV_COL_READY 0x10000 /* i2l_conv_f32_bwd: the workspace is the one the matching i2l_conv_f32_fwd call used and
                                           nothing has written to it since, so its head still holds the column image of x: skip
                                           the im2col launch (the caller keeps one workspace per unit on its tape)               */
+#define I2L_FLAG_RESNET_NO_PATCH 0x20000 /* i2l_conv_bn_act_bf16_fwd, 3x3 / stride 1 / pad 1: the implicit-GEMM ring kernel instead of
+                                          the kernel that stages the input patch in LDS (A/B switch) */
 #define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
                                           implicit-im2col GEMM instead of the sparse first-block kernel (A/B, tests)   */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
+#define I2L_FLAG_RESNET_PATCH_SHAPE(n) (((n) & 0xF) << 20) /* 3x3 / stride 1 layers: force tile shape n (1..5: 160x128, 96x128,
+                                                              128x128, 320x64, 256x64 pixels x channels); 0 = by balance */
 
 int i2l_version(void);
 const char* i2l_error_string(int code);

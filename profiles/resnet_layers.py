@@ -37,7 +37,10 @@ def main():
     L = _lib.lib()
     dev = torch.device("cuda:0")
     total = 0.0
+    only = os.environ.get("ONLY")
     for name, H, W, Cin, Cout, k, s, pd, res, cnt in LAYERS:
+        if only and name not in only.split(","):
+            continue
         Ho, Wo = (H + 2 * pd - k) // s + 1, (W + 2 * pd - k) // s + 1
         x = (torch.randn(B, H, W, Cin, device=dev) * 0.5).to(torch.bfloat16)
         w = torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5

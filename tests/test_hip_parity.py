@@ -525,6 +525,11 @@ BF16_CONV_CASES = [
     (5, 6, 6, 128, 72, 1, 1, 0, 1, 0), (2, 6, 6, 64, 200, 3, 1, 1, 1, 0), (1, 4, 5, 2048, 512, 1, 1, 0, 0, 0),
     (3, 18, 75, 3, 64, 7, 2, 3, 0, 1), (2, 64, 320, 3, 64, 7, 2, 3, 0, 1), (2, 12, 12, 3, 32, 7, 2, 3, 0, 1),
     (2, 9, 9, 32, 64, 3, 1, 1, 1, 0),
+    # 3x3 / stride 1 on the LDS-patch kernel (csrc/resnet_patch.inc.h): tile rows that straddle images (H < rows per tile),
+    # a grid that is not a multiple of the tile, wide rows (one row per tile), residual, 64- and 128-channel tiles
+    (12, 2, 10, 128, 128, 3, 1, 1, 0, 0), (3, 4, 20, 64, 256, 3, 1, 1, 1, 0), (2, 16, 80, 64, 64, 3, 1, 1, 0, 0),
+    (1, 8, 100, 64, 128, 3, 1, 1, 0, 0), (5, 3, 7, 64, 128, 3, 1, 1, 1, 0), (1, 3, 200, 64, 64, 3, 1, 1, 0, 0),
+    (7, 1, 13, 128, 64, 3, 1, 1, 0, 0),
 ]
 
 
@@ -561,6 +566,8 @@ def test_bf16_conv_bn_act_vs_torch(case):
     # every kernel behind the entry point: automatic choice, single-buffered GEMM, forced ring depths, im2col stem
     variants = [0, _lib.FLAG_RESNET_NO_RING, _lib.flag_resnet_ring_depth(2), _lib.flag_resnet_ring_depth(3),
                 _lib.flag_resnet_ring_depth(4), _lib.FLAG_RESNET_IM2COL_STEM]
+    if k == 3 and s == 1 and pd == 1:     # the patch kernel's five tile shapes (a shape that does not fit falls back) and its switch
+        variants += [_lib.flag_resnet_patch_shape(n) for n in range(1, 6)] + [_lib.FLAG_RESNET_NO_PATCH]
     for flags in variants:
         y.fill_(float("nan"))
         wsb = L.i2l_conv_bf16_workspace_bytes(B, H, W, Cin, Cout, k, k, s, pd, flags)
