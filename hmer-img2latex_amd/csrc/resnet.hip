@@ -837,7 +837,14 @@ extern "C" int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const 
     // short reductions (K <= 128: the 1x1 convs of layer1 / layer2 that expand 64 / 128 channels) are bound by HBM, not by
     // the matrix cores: 64-column tiles at THREE workgroups per CU (48 KB of LDS, <= 168 registers) keep more bytes in flight
     const bool short_k = direct && Kp <= 256 && !((flags >> 8) & 0xF) && (long)i2l_cdiv((int)M, GM) * i2l_cdiv(Cout, 64) >= 1024;
-    const int gn = (Cout <= 64 || short_k) ? 64 : 128;     // narrow tile for the 64-channel layers (no wasted MFMAs)
+    int gn = (Cout <= 64 || short_k) ? 64 : 128;           // narrow tile for the 64-channel layers (no wasted MFMAs)
+    if (gn == 128 && Cout % 128 == 0 && !(flags & I2L_FLAG_RESNET_WIDE_TILES)) {
+        // balance: the layers of the trunk are one to five 128 x 128 tiles per CU, so the busiest CU decides (MFMAs alone take
+        // 26 us where the mean load would take 17, profiles/r04/resnet_patch.txt): 64-column tiles when they lower its share
+        const long t128 = (long)i2l_cdiv((int)M, GM) * (Cout / 128);
+        const long c128 = ((t128 + 255) / 256) * 2, c64 = (2 * t128 + 255) / 256;
+        if (c64 < c128) gn = 64;
+    }
     if (implicit && kh == 3 && kw == 3 && stride == 1 && pad == 1 && !(flags & (I2L_FLAG_RESNET_NO_RING | I2L_FLAG_RESNET_NO_PATCH))) {
         // input patch staged in LDS, filters through the ring; the tile shape is picked for balance over the CUs
         const PatchPlan pp = patch_plan((long)M, H, W, Cin, Cout, 256, (flags >> 20) & 0xF);

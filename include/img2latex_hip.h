@@ -77,6 +77,7 @@ typedef void* i2l_stream_t;
 #define I2L_FLAG_CONV_COL_READY 0x10000 /* i2l_conv_f32_bwd: the workspace is the one the matching i2l_conv_f32_fwd call used and
                                           nothing has written to it since, so its head still holds the column image of x: skip
                                           the im2col launch (the caller keeps one workspace per unit on its tape)               */
+#define I2L_FLAG_RESNET_WIDE_TILES 0x40000 /* i2l_conv_bn_act_bf16_fwd: 128-column tiles even where 64-column tiles balance the CUs better (A/B) */
 #define I2L_FLAG_RESNET_NO_PATCH 0x20000 /* i2l_conv_bn_act_bf16_fwd, 3x3 / stride 1 / pad 1: the implicit-GEMM ring kernel instead of
                                           the kernel that stages the input patch in LDS (A/B switch) */
 #define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
