@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(GemmArgs g, float* 
     const int L = blockIdx.x;
     int tile, slice;
     if ((S & 7) == 0) { const int grp = L >> 3; tile = grp % tiles; slice = (L & 7) + 8 * (grp / tiles); }
-    else { tile = L % tiles; slice = L / tiles; }
+    else if (S == 1 && (tiles & 7) == 0) { tile = (L & 7) * (tiles >> 3) + (L >> 3); slice = 0; }   // an XCD walks its own rows of A:
+    else { tile = L % tiles; slice = L / tiles; }                                                   // every N tile of a row block in one L2 (r04: -1.2 % on the training step)
     if (slice >= S) return;
     const int m0 = (tile / tiles_n) * LBM_, n0 = (tile % tiles_n) * LBN;
     // the reduction runs over the flattened (operand pair z, k) range; K % 32 == 0 when nz > 1, so a chunk never

@@ -603,6 +603,7 @@ TLayout make_tlayout(int B, int T, int V, int E, int H, int L) {
     mx(i2l_gemm_workspace_bytes((int)G, 2 * E, (int)BT));     // dW_ih0
     mx(i2l_gemm_workspace_bytes((int)G, H, (int)BT));         // dW_hh / dW_ih_l
     mx(i2l_gemm_workspace_bytes((int)BT, 2 * E, (int)G));     // dX
+    mx(i2l_gemm_workspace_bytes((int)BT, E, (int)G));         // dX, one half (embedding / encoder columns)
     o.gemm_ws = off;
     o.gemm_ws_bytes = i2l_align(g);
     off += o.gemm_ws_bytes;
@@ -935,23 +936,35 @@ extern "C" int i2l_decoder_train_bwd(const i2l_decoder_weights* w, const int32_t
         rc = colsum(DGl, BT, G, colpart_w, gr->b_ih[l], gr->b_hh[l], s_w);
         if (rc != I2L_OK) return rc;
     }
-    {   // dX[bt][k] = sum_n DG0[bt][n] * W_ih_0[n][k]
+    // dX[bt][k] = sum_n DG0[bt][n] * W_ih_0[n][k].  Its ENCODER half (k >= E) feeds dEnc, the head of the encoder's backward
+    // pass; its EMBEDDING half only feeds dEmb, which nothing waits for before the optimizer.  With a side lane the halves are
+    // two GEMMs: the encoder half here, the embedding half + scatter on the lane behind the weight gradients (r04: the dX
+    // GEMM was 95 us on the step's critical path, the half is 47).  Same products and sums either way.
+    // (Always two GEMMs, so that the numbers do not depend on whether a lane is there.)
+    hipStream_t s_e = (side && s_w != s) ? s_w : s;
+    for (int half = 0; half < 2; ++half) {
         GemmArgs g = gemm_args();
         g.split_bf16 = split;   // training GEMMs: bf16 matrix cores with 3-way split operands (fp32-grade), gemm.hip
         g.A = F(lo.DG[0]); g.lda = G;
-        g.W = w->w_ih[0]; g.ldw = 2 * E; g.w_kc = 0;
-        g.C = F(lo.dX); g.ldc = 2 * E;
-        g.M = (int)BT; g.N = 2 * E; g.K = G;
-        rc = i2l_gemm(g, gws, lo.gemm_ws_bytes, s);
+        g.ldw = 2 * E; g.w_kc = 0;
+        g.ldc = 2 * E;
+        g.M = (int)BT; g.N = E; g.K = G;
+        if (half == 0) {
+            g.W = w->w_ih[0] + E; g.C = F(lo.dX) + E;
+            rc = i2l_gemm(g, gws, lo.gemm_ws_bytes, s);
+        } else {
+            g.W = w->w_ih[0]; g.C = F(lo.dX);
+            rc = i2l_gemm(g, s_e == s ? gws : gws_w, lo.gemm_ws_bytes, s_e);
+        }
         if (rc != I2L_OK) return rc;
     }
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for((size_t)V * E)), dim3(256), 0, s, gr->embedding, (size_t)V * E, 0.f);
-    I2L_CHECK_LAUNCH();
-    hipLaunchKernelGGL(emb_scatter_kernel, dim3(grid_for(BT * E)), dim3(256), 0, s, (const float*)F(lo.dX), tokens,
-                       gr->embedding, BT, E, V, dropout_p, (unsigned long long)seed, attention_path);
-    I2L_CHECK_LAUNCH();
     hipLaunchKernelGGL(denc_reduce_kernel, dim3(i2l_cdiv(B * E, 32)), dim3(256), 0, s, (const float*)F(lo.dX),
                        denc_out, B, T, E, dropout_p, (unsigned long long)seed, attention_path);
+    I2L_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for((size_t)V * E)), dim3(256), 0, s_e, gr->embedding, (size_t)V * E, 0.f);
+    I2L_CHECK_LAUNCH();
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(grid_for(BT * E)), dim3(256), 0, s_e, (const float*)F(lo.dX), tokens,
+                       gr->embedding, BT, E, V, dropout_p, (unsigned long long)seed, attention_path);
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }
