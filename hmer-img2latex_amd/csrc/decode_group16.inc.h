@@ -153,30 +153,11 @@ __global__ __launch_bounds__(G16NT, 2) void decode_group16_kernel(GroupParams p)
     const int unit = 16 * m + 4 * wave + uq;                 // ... and its hidden unit
     const int ltile = wave & 1, lhalf = wave >> 1;           // logits: column tile, half of the reduction
 
-    // ---- the member's weights, pre-split in B-operand layout by pack16_kernel: 36 coalesced 16-byte loads per lane
-    bf16x8_t wg[24], wl[12];                                 // [k-step][piece]
-    {
-        const u32x4_t* pk = static_cast<const u32x4_t*>(w.wpack16) + (size_t)(m * 4 + wave) * 36 * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 24; ++i) { Frag16 f; f.q = pk[i * 64]; wg[i] = f.v; }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { Frag16 f; f.q = pk[(24 + i) * 64]; wl[i] = f.v; }
-    }
-    for (int idx = tid; idx < 2 * 3 * G16_HP_PIECE / 2; idx += G16NT) reinterpret_cast<unsigned*>(hp)[idx] = 0u;   // h(-1) = 0
-    if (tid < 32) redk[tid] = 0;
-    if (tid < 8) cnt_s[tid] = 0;
-    const float4 genc = *reinterpret_cast<const float4*>(w.Genc + (size_t)min(row0 + cell_row, B - 1) * G + 4 * unit);
-    const float l_bias = w.boutP[32 * m + 16 * ltile + lcol];
-    float c_own = 0.f, h_own = 0.f;
-    unsigned fin = 0;
-#pragma unroll
-    for (int r = 0; r < G16Q; ++r)
-        if (row0 + r >= B) fin |= 1u << r;
+    // ---- placement exchange FIRST (r04): a member reports itself before it loads its 147 KB of weights, so that the launch's
+    // residency word (count_resident_group) -- which the next batch's encoder stream is waiting for -- is published ~10 us
+    // earlier; waves 1-3 start their weight loads meanwhile
     u64_t* xg = p.xchg + (size_t)group * 2 * G16Q * G16GRAN;
-    const bool own_row = row0 + m < B;
-    int32_t* ids_row = (p.ids && own_row) ? p.ids + (size_t)(row0 + m) * T : nullptr;
-
-    __syncthreads();
+    if (tid < 8) cnt_s[tid] = 0;                             // wave 0: in program order before its writes below
     if (wave == 0) {                                        // placement: are the sixteen members on one XCD?
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -209,6 +190,27 @@ __global__ __launch_bounds__(G16NT, 2) void decode_group16_kernel(GroupParams p)
             }
         }
     }
+    // ---- the member's weights, pre-split in B-operand layout by pack16_kernel: 36 coalesced 16-byte loads per lane
+    bf16x8_t wg[24], wl[12];                                 // [k-step][piece]
+    {
+        const u32x4_t* pk = static_cast<const u32x4_t*>(w.wpack16) + (size_t)(m * 4 + wave) * 36 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { Frag16 f; f.q = pk[i * 64]; wg[i] = f.v; }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { Frag16 f; f.q = pk[(24 + i) * 64]; wl[i] = f.v; }
+    }
+    for (int idx = tid; idx < 2 * 3 * G16_HP_PIECE / 2; idx += G16NT) reinterpret_cast<unsigned*>(hp)[idx] = 0u;   // h(-1) = 0
+    if (tid < 32) redk[tid] = 0;
+    const float4 genc = *reinterpret_cast<const float4*>(w.Genc + (size_t)min(row0 + cell_row, B - 1) * G + 4 * unit);
+    const float l_bias = w.boutP[32 * m + 16 * ltile + lcol];
+    float c_own = 0.f, h_own = 0.f;
+    unsigned fin = 0;
+#pragma unroll
+    for (int r = 0; r < G16Q; ++r)
+        if (row0 + r >= B) fin |= 1u << r;
+    const bool own_row = row0 + m < B;
+    int32_t* ids_row = (p.ids && own_row) ? p.ids + (size_t)(row0 + m) * T : nullptr;
+
     __syncthreads();
     const bool local = cnt_s[3] != 0 && !p.opts.agent_scope;
 
