@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_bf16_ring_kernel(BfGemm g, int 
 }
 
 #include "resnet_patch.inc.h"
+#include "resnet_join.inc.h"
 
 // ------------------------------------------------------------------ fused stem (7x7, stride 2, pad 3, 3 -> 64)
 // conv1 + bn1 + relu straight from the fp32 NCHW images to NHWC bf16: no im2col image in HBM (that image is
@@ -885,6 +886,43 @@ extern "C" int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return I2L_ERR_ARG;
     hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(i2l_cdiv(C % 8 == 0 ? B * (C / 8) : B * C, 256)), dim3(256), 0, i2l_s(stream),
                        static_cast<const bf16_t*>(x), y, B, C, H * W);
+    I2L_CHECK_LAUNCH();
+    return I2L_OK;
+}
+
+// Bottleneck tail + the next block's head in one launch (resnet_join.inc.h): y = relu(bn3(conv3(o2)) + identity), NHWC bf16,
+// and z = relu(bn1'(conv1'(y))).  `packed3` / `packed1_next` come from i2l_conv_bn_bf16_pack for the two 1x1 convs.  Built for
+// the shapes whose y tile fits in LDS beside its filters: c_mid = 64 -> c_out = 256 -> n2 = 64 or 128 (layer1 of the bottleneck
+// ResNets, and its hand-over to layer2); anything else returns I2L_ERR_UNSUPPORTED and the caller makes two launches.
+extern "C" int i2l_bottleneck_join_bf16_fwd(const void* o2, const void* packed3, const void* identity, void* y,
+                                             const void* packed1_next, void* z, long positions, int c_mid, int c_out, int n2,
+                                             i2l_stream_t stream) {
+    if (!o2 || !packed3 || !identity || !y || !packed1_next || !z || positions <= 0) return I2L_ERR_ARG;
+    if (c_mid != 64 || c_out != 256 || (n2 != 64 && n2 != 128) || positions > 0x7fffffffL) return I2L_ERR_UNSUPPORTED;
+    const PackLayout l3 = pack_layout(c_out, c_mid, 1, 1), l1 = pack_layout(n2, c_out, 1, 1);
+    const char* p3 = static_cast<const char*>(packed3);
+    const char* p1 = static_cast<const char*>(packed1_next);
+    JoinArgs g{};
+    g.A1 = static_cast<const bf16_t*>(o2);
+    g.W1 = reinterpret_cast<const bf16_t*>(p3 + l3.wp);
+    g.scale1 = reinterpret_cast<const float*>(p3 + l3.scale); g.bias1 = reinterpret_cast<const float*>(p3 + l3.bias);
+    g.res = static_cast<const bf16_t*>(identity); g.Y = static_cast<bf16_t*>(y);
+    g.W2 = reinterpret_cast<const bf16_t*>(p1 + l1.wp);
+    g.scale2 = reinterpret_cast<const float*>(p1 + l1.scale); g.bias2 = reinterpret_cast<const float*>(p1 + l1.bias);
+    g.Z = static_cast<bf16_t*>(z);
+    g.M = (int)positions;
+    g.n_tiles = i2l_cdiv((int)positions, JN_TM);
+    const dim3 grid((unsigned)(g.n_tiles < 256 ? g.n_tiles : 256));      // one persistent workgroup per CU walks the tiles
+    hipStream_t s = i2l_s(stream);
+    if (n2 == 64) {
+        static std::atomic<unsigned> attr{0};
+        if (!i2l_lds_attr(reinterpret_cast<const void*>(bottleneck_join_kernel<1>), join_lds_bytes(64), attr)) return I2L_ERR_LAUNCH;
+        hipLaunchKernelGGL(bottleneck_join_kernel<1>, grid, dim3(256), join_lds_bytes(64), s, g);
+    } else {
+        static std::atomic<unsigned> attr{0};
+        if (!i2l_lds_attr(reinterpret_cast<const void*>(bottleneck_join_kernel<2>), join_lds_bytes(128), attr)) return I2L_ERR_LAUNCH;
+        hipLaunchKernelGGL(bottleneck_join_kernel<2>, grid, dim3(256), join_lds_bytes(128), s, g);
+    }
     I2L_CHECK_LAUNCH();
     return I2L_OK;
 }

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "i2l_conv_bf16_workspace_bytes": (c_size_t, [c_int] * 10),
     "i2l_conv_bn_act_bf16_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 10 +
                                  [c_void_p, c_size_t, c_int, c_void_p]),
+    "i2l_bottleneck_join_bf16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long,
+                                             c_int, c_int, c_int, c_void_p]),
     "i2l_maxpool3x3s2_bf16_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_global_avgpool_bf16_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -111,6 +111,11 @@ class ResNetEncoder(nn.Module):
         self.cache_packed_weights = True
         self.kernel_flags = 0      # _lib.FLAG_RESNET_NO_RING / FLAG_RESNET_IM2COL_STEM / flag_resnet_ring_depth(n)
         self.trace = None          # a list here receives (conv, bn, x, residual, y, relu, nchw_f32) of every launch
+        self.joined_heads = []     # with trace: the conv1 modules whose input came from a join (never read back from HBM)
+        # layer1: conv3 + identity + ReLU and the next block's conv1 in one launch (i2l_bottleneck_join_bf16_fwd, r04).  OFF by
+        # default: bit-identical, saves a 168 MB read per block, and is still SLOWER than the two launches (117 - 134 us against
+        # 103 - 125 at B=256: one workgroup per CU walks its tiles phase by phase; profiles/r04/resnet_patch.txt, 8)
+        self.fuse_joins = False
         self.trace_bwd = None      # a list here receives every unit's backward: dict(unit, dy, dz, dx, dres, names)
 
     # ------------------------------------------------------------------
@@ -162,6 +167,31 @@ class ResNetEncoder(nn.Module):
         self._packed[id(conv)] = (key, buf)
         return buf
 
+    def _join(self, o, shape, blk, identity, nxt):
+        """conv3 + bn3 + identity + ReLU of `blk` and conv1 + bn1 + ReLU of the next block in one launch
+        (i2l_bottleneck_join_bf16_fwd) where the block output's tile fits in LDS: 64 -> 256 -> 64 | 128 channels, i.e. layer1 of
+        the bottleneck ResNets and its hand-over to layer2.  Returns (y, y_shape, (z, z_shape)) or None (two launches)."""
+        if nxt is None or not isinstance(nxt, _Bottleneck):
+            return None
+        c3, c1 = blk.conv3, nxt.conv1
+        if (c3.in_channels, c3.out_channels) != (64, 256) or c1.in_channels != 256 or c1.out_channels not in (64, 128):
+            return None
+        if c3.stride[0] != 1 or c1.stride[0] != 1 or c1.kernel_size[0] != 1:
+            return None
+        B, H, W, _ = shape
+        L = _lib.lib()
+        y = torch.empty((B, H, W, 256), dtype=torch.bfloat16, device=o.device)
+        z = torch.empty((B, H, W, c1.out_channels), dtype=torch.bfloat16, device=o.device)
+        _lib.check(L.i2l_bottleneck_join_bf16_fwd(
+            o.data_ptr(), self._packed_weights(c3, blk.bn3, o.device).data_ptr(), identity.data_ptr(), y.data_ptr(),
+            self._packed_weights(c1, nxt.bn1, o.device).data_ptr(), z.data_ptr(), B * H * W, 64, 256, c1.out_channels,
+            _lib.stream_ptr()), "bottleneck_join_bf16_fwd")
+        if self.trace is not None:                    # the same two records the two launches would leave
+            self.trace.append((c3, blk.bn3, o, identity, y, True, False))
+            self.trace.append((c1, nxt.bn1, y, None, z, True, False))
+            self.joined_heads.append(c1)              # ... whose input was not read back from HBM
+        return y, (B, H, W, 256), (z, (B, H, W, c1.out_channels))
+
     def trunk(self, x: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) fp32 -> (B, 512|2048) fp32: the torchvision trunk incl. global average pooling."""
         if self.training:
@@ -179,21 +209,32 @@ class ResNetEncoder(nn.Module):
         p = torch.empty((B, Ho, Wo, Ch), dtype=torch.bfloat16, device=x.device)
         _lib.check(L.i2l_maxpool3x3s2_bf16_fwd(h.data_ptr(), p.data_ptr(), B, Hh, Wh, Ch, _lib.stream_ptr()), "maxpool")
         h, shp = p, (B, Ho, Wo, Ch)
-        for li in range(4, 8):
-            for blk in m[li]:
-                identity, ishp = h, shp
-                if isinstance(blk, _Bottleneck):
-                    o, s1 = self._conv_bn(h, shp, blk.conv1, blk.bn1, relu=True)
-                    o, s2 = self._conv_bn(o, s1, blk.conv2, blk.bn2, relu=True)
-                    if blk.downsample is not None:
-                        identity, _ = self._conv_bn(h, shp, blk.downsample[0], blk.downsample[1], relu=False)
-                    h, shp = self._conv_bn(o, s2, blk.conv3, blk.bn3, relu=True, residual=identity)
+        blocks = [blk for li in range(4, 8) for blk in m[li]]
+        layer_end = {id(m[li][-1]): li - 3 for li in range(4, 8)}
+        head = None                                   # (o, shape): this block's conv1 output, already made by the previous block's join
+        for bi, blk in enumerate(blocks):
+            identity, ishp = h, shp
+            if isinstance(blk, _Bottleneck):
+                if head is not None:
+                    (o, s1), head = head, None
                 else:
                     o, s1 = self._conv_bn(h, shp, blk.conv1, blk.bn1, relu=True)
-                    if blk.downsample is not None:
-                        identity, _ = self._conv_bn(h, shp, blk.downsample[0], blk.downsample[1], relu=False)
-                    h, shp = self._conv_bn(o, s1, blk.conv2, blk.bn2, relu=True, residual=identity)
-            _lib.mark(f"layer{li - 3}")
+                o, s2 = self._conv_bn(o, s1, blk.conv2, blk.bn2, relu=True)
+                if blk.downsample is not None:
+                    identity, _ = self._conv_bn(h, shp, blk.downsample[0], blk.downsample[1], relu=False)
+                nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+                joined = self._join(o, s2, blk, identity, nxt) if self.fuse_joins else None
+                if joined is not None:
+                    h, shp, head = joined
+                else:
+                    h, shp = self._conv_bn(o, s2, blk.conv3, blk.bn3, relu=True, residual=identity)
+            else:
+                o, s1 = self._conv_bn(h, shp, blk.conv1, blk.bn1, relu=True)
+                if blk.downsample is not None:
+                    identity, _ = self._conv_bn(h, shp, blk.downsample[0], blk.downsample[1], relu=False)
+                h, shp = self._conv_bn(o, s1, blk.conv2, blk.bn2, relu=True, residual=identity)
+            if id(blk) in layer_end:
+                _lib.mark(f"layer{layer_end[id(blk)]}")
         Bf, Hf, Wf, Cf = shp
         feat = torch.empty((B, Cf), dtype=torch.float32, device=x.device)
         _lib.check(L.i2l_global_avgpool_bf16_fwd(h.data_ptr(), feat.data_ptr(), B, Hf, Wf, Cf, _lib.stream_ptr()), "avgpool")

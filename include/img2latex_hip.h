@@ -187,6 +187,15 @@ int i2l_conv_bn_act_bf16_fwd(const void* x, int x_is_nchw_f32, const void* packe
                              int pad, int relu, void* workspace, size_t workspace_bytes, int flags,
                              i2l_stream_t stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) on NHWC bf16: (B,H,W,C) -> (B,(H-1)/2+1,(W-1)/2+1,C). */
+/* Bottleneck tail + the next block's head in ONE launch (r04; encoder.py:185-249, torchvision Bottleneck.forward's
+ * `out = relu(bn3(conv3(out)) + identity)` followed by the next block's `relu(bn1(conv1(x)))`):
+ *   y[p][256] = relu(bn3(conv3(o2[p][64])) + identity[p][256]),  z[p][n2] = relu(bn1'(conv1'(y[p])))      NHWC bf16
+ * The 128-position tile of y is completed in LDS, written out once (the next block's identity) and multiplied by conv1'
+ * from LDS, so y is not read back: layer1 of the bottleneck ResNets is bound by exactly those bytes.  `packed3` /
+ * `packed1_next` = i2l_conv_bn_bf16_pack of the two 1x1 convs.  Same roundings as the two launches it replaces (bit-identical
+ * y and z).  Shapes: c_mid 64, c_out 256, n2 64 or 128; otherwise I2L_ERR_UNSUPPORTED (the caller makes two launches). */
+int i2l_bottleneck_join_bf16_fwd(const void* o2, const void* packed3, const void* identity, void* y, const void* packed1_next,
+                                 void* z, long positions, int c_mid, int c_out, int n2, i2l_stream_t stream);
 int i2l_maxpool3x3s2_bf16_fwd(const void* x, void* y, int B, int H, int W, int C, i2l_stream_t stream);
 /* nn.AdaptiveAvgPool2d(1) + Flatten: NHWC bf16 (B,H,W,C) -> fp32 (B,C). */
 int i2l_global_avgpool_bf16_fwd(const void* x, float* y, int B, int H, int W, int C, i2l_stream_t stream);

@@ -584,6 +584,51 @@ def test_bf16_conv_bn_act_vs_torch(case):
         assert float(((o - outs[0]).abs() - 2.0 ** -7 * outs[0].abs()).max()) <= 1e-3
 
 
+@pytest.mark.parametrize("n2,shape", [(64, (3, 5, 20)), (128, (2, 16, 80)), (64, (1, 1, 1)), (128, (5, 7, 37))])
+def test_bottleneck_join_equals_two_launches(n2, shape):
+    """i2l_bottleneck_join_bf16_fwd (conv3 + bn3 + identity + ReLU, then the next block's conv1 + bn1 + ReLU, the block output's
+    tile never read back from HBM; encoder.py:185-249) against the two i2l_conv_bn_act_bf16_fwd launches it replaces: the same
+    roundings in the same order, so y and z are bit-identical -- ragged position counts, both head widths; other shapes are
+    refused with I2L_ERR_UNSUPPORTED so that the caller falls back to two launches."""
+    B, H, W = shape
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(100 + n2 + B * H * W)
+    dv = lambda t: t.contiguous().to(DEV)
+    o2 = dv((torch.randn(B, H, W, 64, generator=g) * 0.7).to(torch.bfloat16))
+    ident = dv(torch.randn(B, H, W, 256, generator=g).to(torch.bfloat16))
+
+    def packed(cout, cin):
+        w = dv(torch.randn(cout, cin, 1, 1, generator=g) * cin ** -0.5)
+        gam, bet = dv(torch.rand(cout, generator=g) + 0.5), dv(torch.randn(cout, generator=g) * 0.1)
+        mean, var = dv(torch.randn(cout, generator=g) * 0.1), dv(torch.rand(cout, generator=g) + 0.5)
+        nb = L.i2l_conv_bf16_packed_bytes(cout, cin, 1, 1)
+        buf = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _lib.check(L.i2l_conv_bn_bf16_pack(w.data_ptr(), gam.data_ptr(), bet.data_ptr(), mean.data_ptr(), var.data_ptr(), 1e-5,
+                                           buf.data_ptr(), nb, cout, cin, 1, 1, _lib.stream_ptr()), "pack")
+        return buf
+    p3, p1 = packed(256, 64), packed(n2, 256)
+    ws = torch.empty(4096, dtype=torch.uint8, device=DEV)
+    y_ref = torch.empty(B, H, W, 256, dtype=torch.bfloat16, device=DEV)
+    z_ref = torch.empty(B, H, W, n2, dtype=torch.bfloat16, device=DEV)
+    for flags in (0, _lib.FLAG_RESNET_WIDE_TILES, _lib.FLAG_RESNET_NO_RING):     # whatever tile the two launches take
+        _lib.check(L.i2l_conv_bn_act_bf16_fwd(o2.data_ptr(), 0, p3.data_ptr(), ident.data_ptr(), y_ref.data_ptr(), B, H, W, 64, 256,
+                                              1, 1, 1, 0, 1, ws.data_ptr(), 4096, flags, _lib.stream_ptr()), "conv3")
+        _lib.check(L.i2l_conv_bn_act_bf16_fwd(y_ref.data_ptr(), 0, p1.data_ptr(), None, z_ref.data_ptr(), B, H, W, 256, n2,
+                                              1, 1, 1, 0, 1, ws.data_ptr(), 4096, flags, _lib.stream_ptr()), "conv1")
+        y = torch.full_like(y_ref, float("nan"))
+        z = torch.full_like(z_ref, float("nan"))
+        _lib.check(L.i2l_bottleneck_join_bf16_fwd(o2.data_ptr(), p3.data_ptr(), ident.data_ptr(), y.data_ptr(), p1.data_ptr(),
+                                                  z.data_ptr(), B * H * W, 64, 256, n2, _lib.stream_ptr()), "join")
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), flags
+        assert torch.equal(z.view(torch.int16), z_ref.view(torch.int16)), flags
+    for bad in ((128, 512, 128), (64, 256, 256), (64, 128, 64)):
+        assert L.i2l_bottleneck_join_bf16_fwd(o2.data_ptr(), p3.data_ptr(), ident.data_ptr(), y.data_ptr(), p1.data_ptr(),
+                                              z.data_ptr(), B * H * W, bad[0], bad[1], bad[2], _lib.stream_ptr()) == -2
+    assert L.i2l_bottleneck_join_bf16_fwd(None, p3.data_ptr(), ident.data_ptr(), y.data_ptr(), p1.data_ptr(), z.data_ptr(),
+                                          B * H * W, 64, 256, n2, _lib.stream_ptr()) == -1
+
+
 @pytest.mark.parametrize("model_name,hw", [("resnet18", (32, 64)), ("resnet50", (64, 96)), ("resnet34", (32, 64)),
                                            ("resnet101", (32, 96)), ("resnet152", (32, 64))])
 def test_resnet_encoder_vs_oracle(model_name, hw):
