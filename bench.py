@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--pipe-encoders", type=int, default=None,
                     help="encoder streams in the pipelined region (default 1; 2 for --mode resnet: two trunks side by side "
                          "fill each other's launch gaps and tile tails)")
+    ap.add_argument("--resnet-joins", action="store_true",
+                    help="--mode resnet: layer1's conv3 + identity + ReLU and the next conv1 in one launch (ResNetEncoder.fuse_joins; A/B)")
     ap.add_argument("--resnet-flags", type=lambda v: int(v, 0), default=0,
                     help="--mode resnet: I2L_FLAG_* bits for the trunk's conv kernels (A/B runs, e.g. 0x60000 = ring kernel "
                          "with 128-column tiles everywhere)")
@@ -751,6 +753,7 @@ def extra_modes(args, world, rank, dev, dist):
         model.load_state_dict(full)
         model = model.to(dev).eval()
         model.encoder.kernel_flags = args.resnet_flags
+        model.encoder.fuse_joins = args.resnet_joins
         images = torch.from_numpy(synth.make_images(Bn, cfg, seed=1234 + rank)).to(dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         enc_ms = []
