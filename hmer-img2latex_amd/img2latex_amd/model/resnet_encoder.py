@@ -74,6 +74,10 @@ def _make_layer(block, inplanes, planes, n, stride):
 
 
 class ResNetEncoder(nn.Module):
+    # kernel flags a pipeline ORs in when SEVERAL trunks are in flight (GreedyPipeline(encoder_streams >= 2)): the tile shapes
+    # that balance one layer over the chip only cost arithmetic intensity when a neighbour fills the idle CUs (r04, measured)
+    MULTI_STREAM_FLAGS = _lib.FLAG_RESNET_WIDE_TILES | _lib.FLAG_RESNET_NO_PATCH
+
     def __init__(self, img_height: int = None, img_width: int = None, channels: int = None,
                  model_name: str = "resnet50", embedding_dim: int = None, freeze_backbone: bool = True):
         super().__init__()

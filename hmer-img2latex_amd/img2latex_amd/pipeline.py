@@ -57,11 +57,12 @@ class GreedyPipeline:
         self.decode_flags = int(decode_flags)
         self.stop, self.select = int(stop), int(select)   # STOP_STICKY + SELECT_SOFTMAX = Predictor.predict_batch's loop
         self.encoder_flags = int(encoder_flags)          # e.g. _lib.FLAG_CONV_ONE_PER_CU while the pipeline runs
-        if len(self.enc_streams) >= 2 and type(model.encoder).__name__ == "ResNetEncoder":
+        if len(self.enc_streams) >= 2:
             # several trunks in flight: a trunk's idle CUs are filled by its neighbour, so the shapes that balance ONE layer over
             # the chip (64-column tiles, the LDS-patch 3x3 kernel: -4 % on a trunk alone) only cost arithmetic intensity here --
             # same box, two trunks + decode: 16.7 M tokens/s with them, 17.0 M with 128-column ring tiles (profiles/r04/resnet_patch.txt)
-            self.encoder_flags |= _lib.FLAG_RESNET_WIDE_TILES | _lib.FLAG_RESNET_NO_PATCH
+            # (ResNetEncoder.MULTI_STREAM_FLAGS = FLAG_RESNET_WIDE_TILES | FLAG_RESNET_NO_PATCH; the CNN encoder has none)
+            self.encoder_flags |= getattr(model.encoder, "MULTI_STREAM_FLAGS", 0)
         # Co-resident mode: the encoder of batch i + 1 is held back until the decode of batch i is RESIDENT, so that the
         # decode's 256 workgroups are on the compute units before the first conv workgroup asks for one.  Launched the other
         # way round -- conv0 of batch i + 1 beside prepare(i), conv1 racing the decode for CUs -- the two kernels fall into a
