@@ -530,6 +530,8 @@ BF16_CONV_CASES = [
     (12, 2, 10, 128, 128, 3, 1, 1, 0, 0), (3, 4, 20, 64, 256, 3, 1, 1, 1, 0), (2, 16, 80, 64, 64, 3, 1, 1, 0, 0),
     (1, 8, 100, 64, 128, 3, 1, 1, 0, 0), (5, 3, 7, 64, 128, 3, 1, 1, 1, 0), (1, 3, 200, 64, 64, 3, 1, 1, 0, 0),
     (7, 1, 13, 128, 64, 3, 1, 1, 0, 0),
+    # 320 tiles of 128 x 128: the balance rule takes 64-column tiles (I2L_FLAG_RESNET_WIDE_TILES keeps the wide ones)
+    (16, 16, 80, 64, 256, 1, 1, 0, 0, 0),
 ]
 
 
@@ -565,7 +567,7 @@ def test_bf16_conv_bn_act_vs_torch(case):
     outs = []
     # every kernel behind the entry point: automatic choice, single-buffered GEMM, forced ring depths, im2col stem
     variants = [0, _lib.FLAG_RESNET_NO_RING, _lib.flag_resnet_ring_depth(2), _lib.flag_resnet_ring_depth(3),
-                _lib.flag_resnet_ring_depth(4), _lib.FLAG_RESNET_IM2COL_STEM]
+                _lib.flag_resnet_ring_depth(4), _lib.FLAG_RESNET_IM2COL_STEM, _lib.FLAG_RESNET_WIDE_TILES]
     if k == 3 and s == 1 and pd == 1:     # the patch kernel's five tile shapes (a shape that does not fit falls back) and its switch
         variants += [_lib.flag_resnet_patch_shape(n) for n in range(1, 6)] + [_lib.FLAG_RESNET_NO_PATCH]
     for flags in variants:
