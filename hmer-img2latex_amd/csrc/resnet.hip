@@ -731,7 +731,7 @@ int launch_ring2(const BfGemm& g, int nb_n, int total, hipStream_t s) {
 }
 template <int NTW>
 int launch_ring(const BfGemm& g, int depth, int nb_n, int total, hipStream_t s) {
-    if (depth == 5) return launch_ring2<NTW, 32, 4>(g, nb_n, total, s);      // experiment: 32-deep K tiles, 4 stages, same LDS as <64, 2>
+    if (depth == 5) return launch_ring2<NTW, 32, 4>(g, nb_n, total, s);      // 32-deep K tiles, 4 stages: the LDS of <64, 2>, +-3 % per layer (r04)
     return depth == 4 ? launch_ring2<NTW, 64, 4>(g, nb_n, total, s)
          : depth == 3 ? launch_ring2<NTW, 64, 3>(g, nb_n, total, s) : launch_ring2<NTW, 64, 2>(g, nb_n, total, s);
 }

@@ -82,7 +82,7 @@ typedef void* i2l_stream_t;
                                           the kernel that stages the input patch in LDS (A/B switch) */
 #define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
                                           implicit-im2col GEMM instead of the sparse first-block kernel (A/B, tests)   */
-#define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..5); 0 = automatic              */
+#define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..4; 5 = four stages of 32-deep K tiles); 0 = automatic */
 #define I2L_FLAG_RESNET_PATCH_SHAPE(n) (((n) & 0xF) << 20) /* 3x3 / stride 1 layers: force tile shape n (1..5: 160x128, 96x128,
                                                               128x128, 320x64, 256x64 pixels x channels); 0 = by balance */
 

@@ -567,7 +567,8 @@ def test_bf16_conv_bn_act_vs_torch(case):
     outs = []
     # every kernel behind the entry point: automatic choice, single-buffered GEMM, forced ring depths, im2col stem
     variants = [0, _lib.FLAG_RESNET_NO_RING, _lib.flag_resnet_ring_depth(2), _lib.flag_resnet_ring_depth(3),
-                _lib.flag_resnet_ring_depth(4), _lib.FLAG_RESNET_IM2COL_STEM, _lib.FLAG_RESNET_WIDE_TILES]
+                _lib.flag_resnet_ring_depth(4), _lib.flag_resnet_ring_depth(5), _lib.FLAG_RESNET_IM2COL_STEM,
+                _lib.FLAG_RESNET_WIDE_TILES]
     if k == 3 and s == 1 and pd == 1:     # the patch kernel's five tile shapes (a shape that does not fit falls back) and its switch
         variants += [_lib.flag_resnet_patch_shape(n) for n in range(1, 6)] + [_lib.FLAG_RESNET_NO_PATCH]
     for flags in variants:
