@@ -84,7 +84,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipe-rows", type=int, default=2, help="decode rows per workgroup in the pipelined region")
     ap.add_argument("--pipe-decoders", type=int, default=1, help="decode streams in the pipelined region")
-    ap.add_argument("--pipe-depth", type=int, default=2, help="batches in flight in the pipelined region")
+    ap.add_argument("--pipe-depth", type=int, default=3,
+                    help="batches in flight in the pipelined region (r04: 3 -- with 2 the host enqueues encoder(i+1) only after it has "
+                         "collected batch i-1, ~100 us into decode(i); with 3 the encoder's wait kernel is already in its queue)")
     ap.add_argument("--pipe-encoders", type=int, default=None,
                     help="encoder streams in the pipelined region (default 1; 2 for --mode resnet: two trunks side by side "
                          "fill each other's launch gaps and tile tails)")
@@ -107,6 +109,8 @@ def main():
                          "split-bf16 v_mfma_f32_16x16x32_bf16 bursts)")
     ap.add_argument("--decode-priority", type=int, default=-1, help="pipelined region: HIP stream priority of the decode stream (-1 = high)")
     ap.add_argument("--encoder-priority", type=int, default=0, help="pipelined region: HIP stream priority of the encoder stream(s)")
+    ap.add_argument("--pipe-trace-every", type=int, default=8,
+                    help="pipelined region: HIP timing events around batches j, j + 1 for every j that is a multiple of this (1 = all)")
     ap.add_argument("--pipe-no-hold", action="store_true",
                     help="pipelined region, A/B: do NOT hold encoder(i+1) back until decode(i) is resident (the dependency "
                          "GreedyPipeline adds in the co-resident mode: i2l_greedy_decode_ex's residency signal + "
@@ -263,8 +267,10 @@ def main():
         # HIP events of the timed region, on the streams the kernels are launched on: the warm-up batches are traced too and
         # dropped below (exactly the last K records are the timed batches)
         pipe.trace = []
+        pipe.trace_every = args.pipe_trace_every
+        first_timed = pipe._batch_no + args.warmup
         elapsed = timed(pipe_step, pipe_drain, hooked=False)          # <- the timed region of `value`
-        pipe_trace, pipe.trace = pipe.trace[-args.steps:], None
+        pipe_trace, pipe.trace = [r for r in pipe.trace if r["batch"] >= first_timed], None
         ids_pipe = last[0].clone()
         serial_elapsed = timed(serial_step, lambda: None, hooked=True)  # per-kernel times, undisturbed
         last[0] = ids_host
@@ -373,9 +379,10 @@ def main():
         dec_ms = np.array([r["dec_start"].elapsed_time(r["dec_end"]) for r in pipe_trace])
         enc_ms = np.array([r["enc_start"].elapsed_time(r["enc_end"]) for r in pipe_trace])
         # encoder(i + 1) must start AFTER decode(i) is on the compute units; offset = its first kernel's start behind the decode launch
-        offs = np.array([a["dec_start"].elapsed_time(b["enc_start"]) for a, b in zip(pipe_trace[:-1], pipe_trace[1:])])
+        pairs = [(a, b) for a, b in zip(pipe_trace[:-1], pipe_trace[1:]) if b["batch"] == a["batch"] + 1]
+        offs = np.array([a["dec_start"].elapsed_time(b["enc_start"]) for a, b in pairs])
         # ... and in the fast schedule the whole encoder(i + 1) ends before decode(i) does (profiles/r03/ramp.txt)
-        inside = np.array([b["enc_end"].elapsed_time(a["dec_end"]) for a, b in zip(pipe_trace[:-1], pipe_trace[1:])])
+        inside = np.array([b["enc_end"].elapsed_time(a["dec_end"]) for a, b in pairs])
         with torch.no_grad():     # the same kernel alone on the chip
             enc_ = model.encoder(images)
             for _ in range(3):
@@ -394,7 +401,9 @@ def main():
                          alone_ms=round(alone_ms, 4), frac_alone=round(costs["decode"]["flops"] / alone_ms / 1e9 / PEAK_FP32_TFLOPS, 4),
                          stretch_beside_encoder=round(float(dec_ms.mean()) / alone_ms, 3),
                          encoder_chain_ms_in_region=round(float(enc_ms.mean()), 4),
-                         measured_in=f"the timed region: HIP events on the decode stream around each of its {len(dec_ms)} launches "
+                         measured_in=f"the timed region: HIP events on the decode stream around {len(dec_ms)} of its {args.steps} launches "
+                                     f"(batches j and j + 1 for every j that is a multiple of {args.pipe_trace_every}: four timing events per batch "
+                                     "cost the pipeline ~0.7 %; --pipe-trace-every 1 times every launch) "
                                      "(alone_ms: the same kernel by itself on the chip, after the region)")
         gst = model.decoder.group_status()
         if gst is not None:

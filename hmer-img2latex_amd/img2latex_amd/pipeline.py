@@ -80,6 +80,8 @@ class GreedyPipeline:
         # measurement hook (bench.py): a list here receives, per submitted batch, the timing events {"enc_start" (behind the
         # wait), "enc_end" (behind prepare), "dec_start", "dec_end" (around the decode launch on ITS stream)}
         self.trace: Optional[list] = None
+        self.trace_every = 1         # with `trace`: batches j and j + 1 for every j that is a multiple of this (1 = every batch); a timing
+                                     # event is a marker packet in the queue, and four per batch cost the pipeline ~1 % (r04)
         self._inflight: Deque[Tuple[torch.cuda.Event, torch.Tensor, torch.Tensor]] = deque()
         self.copy_stream = torch.cuda.Stream(device=dev)     # the ids' device -> host copies (off the decode stream: +1 %)
         self._batch_no = 0
@@ -103,8 +105,9 @@ class GreedyPipeline:
                         self._resident.data_ptr(), self._batch_no - len(self.enc_streams) + 1, self.wait_timeout_us,
                         _lib.stream_ptr()), "stream_wait_value32")
                 rec = None
-                if self.trace is not None:
+                if self.trace is not None and self._batch_no % self.trace_every < 2:      # pairs of consecutive batches
                     rec = {k: torch.cuda.Event(enable_timing=True) for k in ("enc_start", "enc_end", "dec_start", "dec_end")}
+                    rec["batch"] = self._batch_no
                     rec["enc_start"].record(enc_stream)
                     self.trace.append(rec)
                 saved = self.model.encoder.kernel_flags
