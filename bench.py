@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--encoder-priority", type=int, default=0, help="pipelined region: HIP stream priority of the encoder stream(s)")
     ap.add_argument("--pipe-trace-every", type=int, default=8,
                     help="pipelined region: HIP timing events around batches j, j + 1 for every j that is a multiple of this (1 = all)")
+    ap.add_argument("--pipe-late-clear", action="store_true",
+                    help="pipelined region: the decode launch zeroes its exchange region itself, on the decode stream (until r04 v4; A/B)")
     ap.add_argument("--pipe-no-hold", action="store_true",
                     help="pipelined region, A/B: do NOT hold encoder(i+1) back until decode(i) is resident (the dependency "
                          "GreedyPipeline adds in the co-resident mode: i2l_greedy_decode_ex's residency signal + "
@@ -250,7 +252,7 @@ def main():
                               rows_per_workgroup=0 if args.coresident else args.pipe_rows, decode_streams=args.pipe_decoders,
                               decode_flags=args.group_flag if args.coresident else 0,
                               decode_priority=args.decode_priority, encoder_streams=args.pipe_encoders or 1,
-                              encoder_priority=args.encoder_priority, hold_encoder=False if args.pipe_no_hold else None)
+                              encoder_priority=args.encoder_priority, hold_encoder=False if args.pipe_no_hold else None, clear_early=not args.pipe_late_clear)
 
         def pipe_step():
             if pipe.pending() >= pipe.depth:
@@ -1006,7 +1008,7 @@ def extra_modes(args, world, rank, dev, dist):
         n_enc = args.pipe_encoders or 2
         pipe = GreedyPipeline(model, synth.START, synth.END, T, rows_per_workgroup=0, decode_flags=args.group_flag,
                               decode_priority=args.decode_priority, encoder_streams=n_enc,
-                              hold_encoder=False if args.pipe_no_hold else None)
+                              hold_encoder=False if args.pipe_no_hold else None, clear_early=not args.pipe_late_clear)
 
         piped_ids = [None]
 

@@ -1090,7 +1090,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
             hipStream_t gs = i2l_s(stream);
             static std::atomic<unsigned> attr16{0};
             if (i2l_lds_attr(reinterpret_cast<const void*>(decode_group16_kernel), GRP16_LDS, attr16)) {
-                if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
+                if (!(flags & I2L_FLAG_DECODE_REGION_CLEARED) && hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
                 hipLaunchKernelGGL(decode_group16_kernel, dim3(i2l_cdiv(gp.n_groups, 8) * 128), dim3(G16NT), GRP16_LDS, gs, gp);
                 I2L_CHECK_LAUNCH();
                 return I2L_OK;
@@ -1111,7 +1111,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
             hipStream_t gs = i2l_s(stream);
             static std::atomic<unsigned> attr8{0};               // per device
             if (i2l_lds_attr(reinterpret_cast<const void*>(decode_group8_kernel), GRP8_LDS, attr8)) {
-                if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
+                if (!(flags & I2L_FLAG_DECODE_REGION_CLEARED) && hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
                 hipLaunchKernelGGL(decode_group8_kernel, dim3(i2l_cdiv(gp.n_groups, 8) * 64), dim3(G8NT), GRP8_LDS, gs, gp);
                 I2L_CHECK_LAUNCH();
                 return I2L_OK;
@@ -1129,7 +1129,7 @@ int launch_decode(const i2l_decoder_weights* w, const void* workspace, int rows,
         hipStream_t gs = i2l_s(stream);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_group_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRP_LDS) == hipSuccess) {
-            if (hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
+            if (!(flags & I2L_FLAG_DECODE_REGION_CLEARED) && hipMemsetAsync(xb, 0, lo.xchg_bytes, gs) != hipSuccess) return I2L_ERR_LAUNCH;
             hipLaunchKernelGGL(decode_group_kernel, dim3(i2l_cdiv(lo.n_groups, 8) * 32), dim3(GNT), GRP_LDS, gs, gp);
             I2L_CHECK_LAUNCH();
             return I2L_OK;
@@ -1291,6 +1291,12 @@ extern "C" int i2l_beam_decode(const i2l_decoder_weights* w, const void* workspa
 extern "C" size_t i2l_decoder_group_status_offset(int rows, int vocab, int embed, int hidden, int layers) {
     const Layout lo = make_layout(rows, vocab, embed, hidden, layers);
     return lo.xchg_bytes ? lo.xchg : 0;
+}
+
+// Size of the region that starts there (status words + the groups' exchange granules): what a grouped launch zeroes before its
+// kernel -- or the caller, earlier and on another stream, with I2L_FLAG_DECODE_REGION_CLEARED.
+extern "C" size_t i2l_decoder_group_region_bytes(int rows, int vocab, int embed, int hidden, int layers) {
+    return make_layout(rows, vocab, embed, hidden, layers).xchg_bytes;
 }
 
 #ifdef I2L_GROUP_STAMPS

@@ -26,6 +26,7 @@ FLAG_WEIGHTS_PACKED = 0x10          # conv forward: the workspace still holds th
 FLAG_AGENT_SCOPE_EXCHANGE = 0x20
 FLAG_CONV_NO_SPARSE_WGRAD = 0x4000   # first conv block's weight gradient by the implicit-im2col GEMM (A/B)
 FLAG_CONV_COL_READY = 0x10000        # i2l_conv_f32_bwd: the workspace still holds the forward call's column image
+FLAG_DECODE_REGION_CLEARED = 0x2000000  # i2l_greedy_decode_ex: the caller zeroed the group region (status + exchange granules) itself
 FLAG_RESNET_WIDE_TILES = 0x40000      # i2l_conv_bn_act_bf16_fwd: 128-column tiles regardless of balance (A/B switch)
 FLAG_RESNET_NO_PATCH = 0x20000       # i2l_conv_bn_act_bf16_fwd: 3x3 convs on the implicit-GEMM ring kernel (A/B switch)
 FLAG_DECODE_GROUP16 = 0x8000         # greedy decode: 16 members x 16 rows per group, per-step products on the matrix cores (split-bf16 MFMA)
@@ -141,6 +142,7 @@ _SIGNATURES.update({
     "i2l_global_avgpool_f32_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_global_avgpool_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "i2l_decoder_group_status_offset": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "i2l_decoder_group_region_bytes": (c_size_t, [c_int] * 5),
     "i2l_resample_ksize": (c_int, [c_int, c_int, c_int]),
     "i2l_resample_coeffs": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "i2l_resample_coeffs_batch": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),

@@ -34,6 +34,7 @@ class GreedyPipeline:
                  temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
                  decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1,
                  encoder_priority: int = 0, hold_encoder: Optional[bool] = None, wait_timeout_us: float = 20000.0,
+                 clear_early: bool = True,
                  stop: int = _lib.STOP_NONE, select: int = _lib.SELECT_LOGITS):
         self.model = model
         self.start, self.end, self.max_length, self.temperature = start_token_id, end_token_id, max_length, temperature
@@ -75,6 +76,7 @@ class GreedyPipeline:
         if hold_encoder is None:
             hold_encoder = bool(self.decode_flags & (_lib.FLAG_DECODE_GROUP8 | _lib.FLAG_DECODE_GROUP16))
         self.hold_encoder = bool(hold_encoder)
+        self.clear_early = bool(clear_early)             # the decode's group region is zeroed on the encoder stream (see submit)
         self.wait_timeout_us = float(wait_timeout_us)
         self._resident = torch.zeros(1, dtype=torch.int32, device=dev)
         # measurement hook (bench.py): a list here receives, per submitted batch, the timing events {"enc_start" (behind the
@@ -122,8 +124,19 @@ class GreedyPipeline:
                 slot = self._batch_no % self._slots
                 seq = self._batch_no + 1
                 self._batch_no += 1
-                w, keep, enc_c = self.model.decoder.prepare(enc, slot=("pipe", id(self), slot))
-                prepared = (w, keep, enc_c, self.model.decoder._ws)
+                dec = self.model.decoder
+                w, keep, enc_c = dec.prepare(enc, slot=("pipe", id(self), slot))
+                prepared = (w, keep, enc_c, dec._ws)
+                # the grouped launch zeroes its status words + exchange granules first; done HERE, behind prepare on the encoder
+                # stream (which ends before the running decode does), that memset is no longer between two decodes on their queue
+                dflags = self.decode_flags
+                if self.clear_early and dflags & (_lib.FLAG_DECODE_GROUP8 | _lib.FLAG_DECODE_GROUP16):
+                    dims = (enc.shape[0], dec.vocab_size, dec.embedding_dim, dec.hidden_dim, dec.lstm_layers)
+                    off = _lib.lib().i2l_decoder_group_status_offset(*dims)
+                    nb = _lib.lib().i2l_decoder_group_region_bytes(*dims)
+                    if off and nb:
+                        dec._ws[off:off + nb].zero_()
+                        dflags |= _lib.FLAG_DECODE_REGION_CLEARED
                 enc_done = torch.cuda.Event() if rec is None else rec["enc_end"]
                 enc_done.record(enc_stream)
             images.record_stream(enc_stream)
@@ -136,7 +149,7 @@ class GreedyPipeline:
                     rec["dec_start"].record(dec_stream)
                 ids, _ = self.model.greedy_ids(enc, self.start, self.end, self.max_length, self.temperature,
                                                stop=self.stop, select=self.select,
-                                               rows_per_workgroup=self.rows_per_workgroup, flags=self.decode_flags,
+                                               rows_per_workgroup=self.rows_per_workgroup, flags=dflags,
                                                prepared=prepared,
                                                resident=(self._resident, seq) if self.hold_encoder else None)
                 if rec is not None:

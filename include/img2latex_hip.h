@@ -80,6 +80,9 @@ typedef void* i2l_stream_t;
 #define I2L_FLAG_RESNET_WIDE_TILES 0x40000 /* i2l_conv_bn_act_bf16_fwd: 128-column tiles even where 64-column tiles balance the CUs better (A/B) */
 #define I2L_FLAG_RESNET_NO_PATCH 0x20000 /* i2l_conv_bn_act_bf16_fwd, 3x3 / stride 1 / pad 1: the implicit-GEMM ring kernel instead of
                                           the kernel that stages the input patch in LDS (A/B switch) */
+#define I2L_FLAG_DECODE_REGION_CLEARED 0x2000000 /* i2l_greedy_decode_ex, grouped kernels: the caller has zeroed the workspace's group region
+                                             (i2l_decoder_group_status_offset / _region_bytes) since its last use, ordered before this call: the
+                                             launch skips its own memset (GreedyPipeline clears it on the encoder stream, off the decode queue) */
 #define I2L_FLAG_CONV_NO_SPARSE_WGRAD 0x4000 /* i2l_conv3x3_relu_pool2_bwd with dx == NULL, Cin <= 3, Cout % 32 == 0: the
                                           implicit-im2col GEMM instead of the sparse first-block kernel (A/B, tests)   */
 #define I2L_FLAG_RESNET_RING_DEPTH(n) (((n) & 0xF) << 8)   /* force the ring depth (2..4; 5 = four stages of 32-deep K tiles); 0 = automatic */
@@ -484,6 +487,7 @@ int i2l_masked_accuracy(const float* logits, const int64_t* targets, int64_t row
  * exchange in the last launch, [2] of those, the groups whose four workgroups measured themselves on ONE XCD and
  * therefore exchanged through that XCD's L2 (the fast flavour).  Diagnostics: read after synchronising the stream. */
 size_t i2l_decoder_group_status_offset(int rows, int vocab, int embed, int hidden, int layers);
+size_t i2l_decoder_group_region_bytes(int rows, int vocab, int embed, int hidden, int layers);   /* bytes of that region (status + exchange granules) */
 
 /* ------------------------------------------------------------------------
  * Image preprocessing (reference img2latex/data/utils.py:18-90, data/transforms.py:26-56), SURVEY section 8(f)-3
