@@ -269,7 +269,8 @@ def main():
         # HIP events of the timed region, on the streams the kernels are launched on: the warm-up batches are traced too and
         # dropped below (exactly the last K records are the timed batches)
         pipe.trace = []
-        pipe.trace_every = args.pipe_trace_every
+        # sampled timing events only when the region is long enough to hold several traced pairs; short runs time every batch
+        pipe.trace_every = args.pipe_trace_every if args.steps >= 4 * args.pipe_trace_every else 1
         first_timed = pipe._batch_no + args.warmup
         elapsed = timed(pipe_step, pipe_drain, hooked=False)          # <- the timed region of `value`
         pipe_trace, pipe.trace = [r for r in pipe.trace if r["batch"] >= first_timed], None
@@ -404,7 +405,7 @@ def main():
                          stretch_beside_encoder=round(float(dec_ms.mean()) / alone_ms, 3),
                          encoder_chain_ms_in_region=round(float(enc_ms.mean()), 4),
                          measured_in=f"the timed region: HIP events on the decode stream around {len(dec_ms)} of its {args.steps} launches "
-                                     f"(batches j and j + 1 for every j that is a multiple of {args.pipe_trace_every}: four timing events per batch "
+                                     f"(batches j and j + 1 for every j that is a multiple of {pipe.trace_every}: four timing events per batch "
                                      "cost the pipeline ~0.7 %; --pipe-trace-every 1 times every launch) "
                                      "(alone_ms: the same kernel by itself on the chip, after the region)")
         gst = model.decoder.group_status()
