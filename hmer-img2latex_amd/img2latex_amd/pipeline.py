@@ -31,7 +31,7 @@ class GreedyPipeline:
     """submit(images) enqueues one batch; results come back in order from collect()."""
 
     def __init__(self, model, start_token_id: int, end_token_id: int, max_length: int = 150,
-                 temperature: float = 1.0, depth: int = 2, rows_per_workgroup: int = 2, decode_streams: int = 1,
+                 temperature: float = 1.0, depth: int = 3, rows_per_workgroup: int = 2, decode_streams: int = 1,
                  decode_flags: int = 0, encoder_flags: int = 0, decode_priority: int = 0, encoder_streams: int = 1,
                  encoder_priority: int = 0, hold_encoder: Optional[bool] = None, wait_timeout_us: float = 20000.0,
                  clear_early: bool = True,
@@ -50,6 +50,9 @@ class GreedyPipeline:
         # few CUs (more rows per workgroup = less weight traffic per row); depth must cover them
         self.dec_streams = [torch.cuda.Stream(device=dev, priority=int(decode_priority)) for _ in range(max(1, decode_streams))]
         self._next_dec = 0
+        # depth 3 (default since r04): with two batches in flight the host can enqueue encoder(i + 1) only after it has collected
+        # batch i - 1, ~100 us into decode(i) (a kernel trace showed the encoder queue idle that long); with three its kernels
+        # are already queued behind the residency wait when decode(i) is launched
         self.depth = max(depth, len(self.dec_streams) + len(self.enc_streams))
         self.rows_per_workgroup = rows_per_workgroup     # 2: decode occupies half of the CUs, the encoder the rest
         # r03: decode_flags = _lib.FLAG_DECODE_GROUP8 (with rows_per_workgroup = 0) runs the 8-member grouped decode
